@@ -1,0 +1,27 @@
+"""MI355X-native dense-retrieval path of hirag-prod: exact cosine top-k and k-means assignment.
+
+Import as ``hirag_prod_amd`` (the alias module at the repository root maps that name onto this
+directory).  Public surface:
+
+* ``HvsIndex``        -- one embedded table resident in HBM (``index.py``)
+* ``HipVectorStore``  -- drop-in for the reference's ``BaseVDB`` / ``PGVector`` (``store.py``)
+* ``ShardedSearch`` / ``sharded_kmeans_step`` -- one process per GPU over RCCL (``sharded.py``)
+"""
+
+from ._lib import HvsError, device_count, load_library
+from .index import HvsIndex, merge_topk
+
+__all__ = ["HvsError", "HvsIndex", "device_count", "load_library", "merge_topk"]
+
+
+def __getattr__(name):
+    # heavier modules are imported on first use
+    if name in ("HipVectorStore", "BaseVDB"):
+        from . import store
+
+        return getattr(store, name)
+    if name in ("ShardedSearch", "sharded_kmeans_step", "shard_range"):
+        from . import sharded
+
+        return getattr(sharded, name)
+    raise AttributeError(name)

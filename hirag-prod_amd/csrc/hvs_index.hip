@@ -1,0 +1,526 @@
+// Index life cycle, ingest, synthetic fill, gather (C ABI: include/hvs.h).
+#include <cstdarg>
+
+#include "hvs_internal.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void hvs_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *hvs_last_error(void) { return g_last_error.c_str(); }
+extern "C" int hvs_version(void) { return 100; }
+
+extern "C" int hvs_device_count(int *out) {
+    HVS_REQUIRE(out != nullptr, "hvs_device_count: out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <typename SRC, typename DST> __device__ __forceinline__ DST hvs_cvt(SRC v);
+template <> __device__ __forceinline__ float hvs_cvt<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ __half hvs_cvt<float, __half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ __half hvs_cvt<__half, __half>(__half v) { return v; }
+template <> __device__ __forceinline__ uint16_t hvs_cvt<float, uint16_t>(float v) { return hvs_float_to_bf16(v); }
+template <> __device__ __forceinline__ uint16_t hvs_cvt<uint16_t, uint16_t>(uint16_t v) { return v; }
+
+// dst[pos(r)][c] = round(src[r][c]) for c < dim, 0 for dim <= c < ld.  positions == nullptr: pos(r) = first + r.
+template <typename SRC, typename DST>
+__global__ void store_rows_kernel(const SRC *__restrict__ src, DST *__restrict__ dst, int64_t n, int dim, int ld,
+                                  int64_t first, const int64_t *__restrict__ positions) {
+    const int64_t total = n * (int64_t)ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        const int64_t p = positions ? positions[r] : first + r;
+        DST v;
+        if (c < dim) v = hvs_cvt<SRC, DST>(src[r * dim + c]);
+        else v = hvs_cvt<float, DST>(0.0f);
+        dst[p * ld + c] = v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ float hvs_widen(T v);
+template <> __device__ __forceinline__ float hvs_widen<float>(float v) { return v; }
+template <> __device__ __forceinline__ float hvs_widen<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float hvs_widen<uint16_t>(uint16_t v) { return hvs_bf16_to_float(v); }
+
+// one wave per row: inv_norm[p] = 1/sqrt(sum x^2) over the stored (rounded) values; zero row -> +inf
+template <typename T>
+__global__ void inv_norm_kernel(const T *__restrict__ rows, float *__restrict__ inv_norm, int64_t n, int ld,
+                                int64_t first, const int64_t *__restrict__ positions) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        const int64_t p = positions ? positions[r] : first + r;
+        const T *row = rows + p * ld;
+        float s = 0.0f;
+        for (int c = lane; c < ld; c += 64) {
+            const float v = hvs_widen<T>(row[c]);
+            s = fmaf(v, v, s);
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) inv_norm[p] = (float)(1.0 / sqrt((double)s));
+    }
+}
+
+template <typename T>
+__global__ void fill_synth_kernel(T *__restrict__ rows, int64_t n, int dim, int ld, int64_t first_pos,
+                                  int64_t first_global, uint64_t seed_mix) {
+    const int64_t total = n * (int64_t)ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.0f;
+        if (c < dim) {
+            const uint64_t ctr = (uint64_t)(first_global + r) * (uint64_t)dim + (uint64_t)c;
+            const uint64_t h = hvs_splitmix64(ctr ^ seed_mix);
+            const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) +
+                          (int)((h >> 48) & 0xFFFF) - 131070;
+            v = (float)s * (1.0f / 37837.0f);
+        }
+        rows[(first_pos + r) * ld + c] = hvs_cvt<float, T>(v);
+    }
+}
+
+__global__ void fill_meta_kernel(int64_t *ids, int32_t *groups, int64_t n, int64_t first_pos, int64_t first_id,
+                                 int32_t n_groups, const int64_t *src_ids, const int32_t *src_groups) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = src_ids ? src_ids[i] : first_id + i;
+        ids[first_pos + i] = id;
+        int32_t g = 0;
+        if (src_groups) g = src_groups[i];
+        else if (n_groups > 0) g = (int32_t)(id % n_groups);
+        groups[first_pos + i] = g;
+    }
+}
+
+template <typename T>
+__global__ void gather_kernel(const T *__restrict__ rows, const int64_t *__restrict__ positions, int64_t n, int dim,
+                              int ld, float *__restrict__ out) {
+    const int64_t total = n * (int64_t)dim;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / dim;
+        const int c = (int)(i - r * dim);
+        out[i] = hvs_widen<T>(rows[positions[r] * ld + c]);
+    }
+}
+
+__global__ void set_deleted_kernel(uint32_t *bits, const int64_t *positions, int64_t n, int deleted) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = positions[i];
+        if (deleted) atomicOr(&bits[p >> 5], 1u << (p & 31));
+        else atomicAnd(&bits[p >> 5], ~(1u << (p & 31)));
+    }
+}
+
+static inline int grid_for(int64_t work, int block = 256, int max_blocks = 256 * 8) {
+    int64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------
+// workspace / profiling helpers
+// ---------------------------------------------------------------------------
+int hvs_ws_get(hvs_index *idx, int slot, size_t bytes, void **out) {
+    hvs_workspace &w = idx->ws[slot];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+            HVS_HIP(hipFree(w.ptr));
+            w.ptr = nullptr;
+            w.bytes = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        if (want < (1u << 20)) want = 1u << 20;
+        HVS_HIP(hipMalloc(&w.ptr, want));
+        w.bytes = want;
+    }
+    *out = w.ptr;
+    return 0;
+}
+
+int hvs_prof_begin(hvs_index *idx) {
+    if (!idx->profiling) return 0;
+    HVS_HIP(hipEventRecord(idx->ev0, idx->stream));
+    return 0;
+}
+
+int hvs_prof_end(hvs_index *idx, int which) {
+    if (!idx->profiling) return 0;
+    HVS_HIP(hipEventRecord(idx->ev1, idx->stream));
+    HVS_HIP(hipEventSynchronize(idx->ev1));
+    float ms = 0.0f;
+    HVS_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
+    idx->prof_ms[which] += ms;
+    idx->prof_launches[which] += 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" int hvs_index_create(hvs_index **out, int device_id, int dim, int dtype, void *stream) {
+    HVS_REQUIRE(out != nullptr, "hvs_index_create: out is NULL");
+    *out = nullptr;
+    HVS_REQUIRE(dim > 0 && dim <= 65536, "hvs_index_create: dim %d out of range [1, 65536]", dim);
+    HVS_REQUIRE(dtype == HVS_F32 || dtype == HVS_F16 || dtype == HVS_BF16, "hvs_index_create: unknown dtype %d", dtype);
+    int ndev = 0;
+    HVS_TRY(hvs_device_count(&ndev));
+    HVS_REQUIRE(ndev > 0, "hvs_index_create: no HIP device visible (this library has no CPU path)");
+    HVS_REQUIRE(device_id >= 0 && device_id < ndev, "hvs_index_create: device %d not in [0, %d)", device_id, ndev);
+    HVS_HIP(hipSetDevice(device_id));
+    hvs_index *idx = new hvs_index();
+    idx->device = device_id;
+    idx->dim = dim;
+    idx->dtype = dtype;
+    idx->elem_size = hvs_elem_size(dtype);
+    const int per_chunk = 16 / idx->elem_size;
+    idx->ld = (dim + per_chunk - 1) / per_chunk * per_chunk;
+    if (stream) {
+        idx->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            hvs_set_error("hvs_index_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete idx;
+            return 1;
+        }
+        idx->own_stream = true;
+    }
+    hipEventCreate(&idx->ev0);
+    hipEventCreate(&idx->ev1);
+    hipEventCreate(&idx->tm0);
+    hipEventCreate(&idx->tm1);
+    *out = idx;
+    return 0;
+}
+
+extern "C" int hvs_index_destroy(hvs_index *idx) {
+    if (!idx) return 0;
+    (void)hipSetDevice(idx->device);
+    (void)hipStreamSynchronize(idx->stream);
+    hipFree(idx->rows);
+    hipFree(idx->inv_norm);
+    hipFree(idx->ids);
+    hipFree(idx->groups);
+    hipFree(idx->deleted);
+    for (auto &w : idx->ws) hipFree(w.ptr);
+    hipEventDestroy(idx->ev0);
+    hipEventDestroy(idx->ev1);
+    hipEventDestroy(idx->tm0);
+    hipEventDestroy(idx->tm1);
+    if (idx->own_stream) hipStreamDestroy(idx->stream);
+    delete idx;
+    return 0;
+}
+
+template <typename P>
+static int grow(hvs_index *idx, P **ptr, size_t old_count, size_t new_count, bool zero_new = false) {
+    P *np = nullptr;
+    HVS_HIP(hipMalloc((void **)&np, new_count * sizeof(P)));
+    if (*ptr && old_count) HVS_HIP(hipMemcpyAsync(np, *ptr, old_count * sizeof(P), hipMemcpyDeviceToDevice, idx->stream));
+    if (zero_new && new_count > old_count)
+        HVS_HIP(hipMemsetAsync(np + old_count, 0, (new_count - old_count) * sizeof(P), idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    if (*ptr) HVS_HIP(hipFree(*ptr));
+    *ptr = np;
+    return 0;
+}
+
+extern "C" int hvs_index_reserve(hvs_index *idx, int64_t capacity_rows) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_reserve: idx is NULL");
+    HVS_REQUIRE(capacity_rows < (int64_t)0xFFFFFFFFll, "hvs_index_reserve: at most 2^32-1 rows per index");
+    if (capacity_rows <= idx->cap) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    const size_t row_bytes = (size_t)idx->ld * idx->elem_size;
+    {
+        char *np = nullptr;
+        HVS_HIP(hipMalloc((void **)&np, (size_t)capacity_rows * row_bytes));
+        if (idx->rows && idx->n)
+            HVS_HIP(hipMemcpyAsync(np, idx->rows, (size_t)idx->n * row_bytes, hipMemcpyDeviceToDevice, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+        if (idx->rows) HVS_HIP(hipFree(idx->rows));
+        idx->rows = np;
+    }
+    HVS_TRY(grow(idx, &idx->inv_norm, (size_t)idx->n, (size_t)capacity_rows));
+    HVS_TRY(grow(idx, &idx->ids, (size_t)idx->n, (size_t)capacity_rows));
+    HVS_TRY(grow(idx, &idx->groups, (size_t)idx->n, (size_t)capacity_rows));
+    if (idx->deleted)
+        HVS_TRY(grow(idx, &idx->deleted, (size_t)(idx->cap + 31) / 32, (size_t)(capacity_rows + 31) / 32, true));
+    idx->cap = capacity_rows;
+    return 0;
+}
+
+extern "C" int hvs_index_size(hvs_index *idx, int64_t *out_rows) {
+    HVS_REQUIRE(idx && out_rows, "hvs_index_size: NULL argument");
+    *out_rows = idx->n;
+    return 0;
+}
+
+extern "C" int hvs_index_info(hvs_index *idx, int *dim, int *dtype, int *device_id, int64_t *capacity_rows) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_info: idx is NULL");
+    if (dim) *dim = idx->dim;
+    if (dtype) *dtype = idx->dtype;
+    if (device_id) *device_id = idx->device;
+    if (capacity_rows) *capacity_rows = idx->cap;
+    return 0;
+}
+
+extern "C" int hvs_sync(hvs_index *idx) {
+    HVS_REQUIRE(idx != nullptr, "hvs_sync: idx is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+// store n rows from a DEVICE source buffer at [first, first+n) or at positions[]
+static int store_rows_device(hvs_index *idx, const void *src, int src_dtype, int64_t n, int64_t first,
+                             const int64_t *positions) {
+    const int g = grid_for(n * (int64_t)idx->ld);
+    hipStream_t s = idx->stream;
+    if (idx->dtype == HVS_F32) {
+        HVS_REQUIRE(src_dtype == HVS_F32, "rows for an f32 index must be f32");
+        store_rows_kernel<float, float><<<g, 256, 0, s>>>((const float *)src, (float *)idx->rows, n, idx->dim, idx->ld, first, positions);
+        inv_norm_kernel<float><<<grid_for(n * 64), 256, 0, s>>>((const float *)idx->rows, idx->inv_norm, n, idx->ld, first, positions);
+    } else if (idx->dtype == HVS_F16) {
+        if (src_dtype == HVS_F32)
+            store_rows_kernel<float, __half><<<g, 256, 0, s>>>((const float *)src, (__half *)idx->rows, n, idx->dim, idx->ld, first, positions);
+        else if (src_dtype == HVS_F16)
+            store_rows_kernel<__half, __half><<<g, 256, 0, s>>>((const __half *)src, (__half *)idx->rows, n, idx->dim, idx->ld, first, positions);
+        else HVS_REQUIRE(false, "rows for an f16 index must be f32 or f16");
+        inv_norm_kernel<__half><<<grid_for(n * 64), 256, 0, s>>>((const __half *)idx->rows, idx->inv_norm, n, idx->ld, first, positions);
+    } else {
+        if (src_dtype == HVS_F32)
+            store_rows_kernel<float, uint16_t><<<g, 256, 0, s>>>((const float *)src, (uint16_t *)idx->rows, n, idx->dim, idx->ld, first, positions);
+        else if (src_dtype == HVS_BF16)
+            store_rows_kernel<uint16_t, uint16_t><<<g, 256, 0, s>>>((const uint16_t *)src, (uint16_t *)idx->rows, n, idx->dim, idx->ld, first, positions);
+        else HVS_REQUIRE(false, "rows for a bf16 index must be f32 or bf16");
+        inv_norm_kernel<uint16_t><<<grid_for(n * 64), 256, 0, s>>>((const uint16_t *)idx->rows, idx->inv_norm, n, idx->ld, first, positions);
+    }
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int hvs_index_add(hvs_index *idx, const void *rows, int src_dtype, int64_t n, const int64_t *ids,
+                             const int32_t *group_codes, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_add: idx is NULL");
+    HVS_REQUIRE(n >= 0, "hvs_index_add: negative row count");
+    if (n == 0) return 0;
+    HVS_REQUIRE(rows != nullptr, "hvs_index_add: rows is NULL");
+    HVS_REQUIRE(src_dtype == HVS_F32 || src_dtype == idx->dtype, "hvs_index_add: source dtype %d not accepted by index dtype %d", src_dtype, idx->dtype);
+    HVS_HIP(hipSetDevice(idx->device));
+    if (idx->n + n > idx->cap) {
+        int64_t want = idx->cap * 2;
+        if (want < idx->n + n) want = idx->n + n;
+        if (want < 1024) want = 1024;
+        HVS_TRY(hvs_index_reserve(idx, want));
+    }
+    const int64_t first = idx->n;
+    const size_t src_row_bytes = (size_t)idx->dim * hvs_elem_size(src_dtype);
+    if (on_device) {
+        HVS_TRY(store_rows_device(idx, rows, src_dtype, n, first, nullptr));
+        fill_meta_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->ids, idx->groups, n, first, first, 0, ids, group_codes);
+        HVS_HIP(hipGetLastError());
+    } else {
+        // stage through device scratch in slices of <= 128 MiB
+        int64_t slice = (int64_t)((128u << 20) / src_row_bytes);
+        if (slice < 1) slice = 1;
+        for (int64_t off = 0; off < n; off += slice) {
+            const int64_t m = (n - off < slice) ? n - off : slice;
+            void *stage = nullptr;
+            const size_t meta_off = ((size_t)m * src_row_bytes + 255) & ~(size_t)255;
+            HVS_TRY(hvs_ws_get(idx, 3, meta_off + (size_t)m * 12 + 256, &stage));
+            HVS_HIP(hipMemcpyAsync(stage, (const char *)rows + (size_t)off * src_row_bytes, (size_t)m * src_row_bytes, hipMemcpyHostToDevice, idx->stream));
+            int64_t *d_ids = nullptr;
+            int32_t *d_groups = nullptr;
+            if (ids) {
+                d_ids = (int64_t *)((char *)stage + meta_off);
+                HVS_HIP(hipMemcpyAsync(d_ids, ids + off, (size_t)m * 8, hipMemcpyHostToDevice, idx->stream));
+            }
+            if (group_codes) {
+                d_groups = (int32_t *)((char *)stage + meta_off + (size_t)m * 8);
+                HVS_HIP(hipMemcpyAsync(d_groups, group_codes + off, (size_t)m * 4, hipMemcpyHostToDevice, idx->stream));
+            }
+            HVS_TRY(store_rows_device(idx, stage, src_dtype, m, first + off, nullptr));
+            fill_meta_kernel<<<grid_for(m), 256, 0, idx->stream>>>(idx->ids, idx->groups, m, first + off, first + off, 0, d_ids, d_groups);
+            HVS_HIP(hipGetLastError());
+            HVS_HIP(hipStreamSynchronize(idx->stream));  // the stage buffer is reused by the next slice
+        }
+    }
+    idx->n += n;
+    if (!on_device) HVS_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+extern "C" int hvs_index_update(hvs_index *idx, const int64_t *positions, const void *rows, int src_dtype, int64_t n,
+                                int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_update: idx is NULL");
+    if (n <= 0) return 0;
+    HVS_REQUIRE(positions && rows, "hvs_index_update: NULL argument");
+    HVS_REQUIRE(src_dtype == HVS_F32 || src_dtype == idx->dtype, "hvs_index_update: source dtype %d not accepted", src_dtype);
+    HVS_HIP(hipSetDevice(idx->device));
+    const size_t src_row_bytes = (size_t)idx->dim * hvs_elem_size(src_dtype);
+    if (on_device) {
+        HVS_TRY(store_rows_device(idx, rows, src_dtype, n, 0, positions));
+        return 0;
+    }
+    for (int64_t i = 0; i < n; i++)
+        HVS_REQUIRE(positions[i] >= 0 && positions[i] < idx->n, "hvs_index_update: position %lld out of range", (long long)positions[i]);
+    void *stage = nullptr;
+    const size_t pos_off = ((size_t)n * src_row_bytes + 255) & ~(size_t)255;
+    HVS_TRY(hvs_ws_get(idx, 3, pos_off + (size_t)n * 8, &stage));
+    HVS_HIP(hipMemcpyAsync(stage, rows, (size_t)n * src_row_bytes, hipMemcpyHostToDevice, idx->stream));
+    HVS_HIP(hipMemcpyAsync((char *)stage + pos_off, positions, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
+    HVS_TRY(store_rows_device(idx, stage, src_dtype, n, 0, (const int64_t *)((char *)stage + pos_off)));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+extern "C" int hvs_index_set_deleted(hvs_index *idx, const int64_t *positions, int64_t n, int deleted) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_set_deleted: idx is NULL");
+    if (n <= 0) return 0;
+    HVS_REQUIRE(positions != nullptr, "hvs_index_set_deleted: positions is NULL");
+    for (int64_t i = 0; i < n; i++)
+        HVS_REQUIRE(positions[i] >= 0 && positions[i] < idx->n, "hvs_index_set_deleted: position %lld out of range", (long long)positions[i]);
+    HVS_HIP(hipSetDevice(idx->device));
+    if (!idx->deleted) {
+        const size_t words = (size_t)(idx->cap + 31) / 32;
+        HVS_HIP(hipMalloc((void **)&idx->deleted, words * 4));
+        HVS_HIP(hipMemsetAsync(idx->deleted, 0, words * 4, idx->stream));
+    }
+    void *stage = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 3, (size_t)n * 8, &stage));
+    HVS_HIP(hipMemcpyAsync(stage, positions, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
+    set_deleted_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->deleted, (const int64_t *)stage, n, deleted);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    idx->n_deleted += deleted ? n : -n;
+    if (idx->n_deleted < 0) idx->n_deleted = 0;
+    return 0;
+}
+
+extern "C" int hvs_index_fill_synthetic(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row,
+                                        int32_t n_groups) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_fill_synthetic: idx is NULL");
+    HVS_REQUIRE(n >= 0 && first_global_row >= 0, "hvs_index_fill_synthetic: negative argument");
+    if (n == 0) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    if (idx->n + n > idx->cap) HVS_TRY(hvs_index_reserve(idx, idx->n + n));
+    const int64_t first = idx->n;
+    // splitmix64(seed) on the host, same function as the device's
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    const uint64_t seed_mix = z ^ (z >> 31);
+    const int g = grid_for(n * (int64_t)idx->ld, 256, 256 * 16);
+    hipStream_t s = idx->stream;
+    if (idx->dtype == HVS_F32) {
+        fill_synth_kernel<float><<<g, 256, 0, s>>>((float *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, seed_mix);
+        inv_norm_kernel<float><<<grid_for(n * 64), 256, 0, s>>>((const float *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    } else if (idx->dtype == HVS_F16) {
+        fill_synth_kernel<__half><<<g, 256, 0, s>>>((__half *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, seed_mix);
+        inv_norm_kernel<__half><<<grid_for(n * 64), 256, 0, s>>>((const __half *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    } else {
+        fill_synth_kernel<uint16_t><<<g, 256, 0, s>>>((uint16_t *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, seed_mix);
+        inv_norm_kernel<uint16_t><<<grid_for(n * 64), 256, 0, s>>>((const uint16_t *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    }
+    HVS_HIP(hipGetLastError());
+    fill_meta_kernel<<<grid_for(n), 256, 0, s>>>(idx->ids, idx->groups, n, first, first_global_row, n_groups, nullptr, nullptr);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipStreamSynchronize(s));
+    idx->n += n;
+    return 0;
+}
+
+extern "C" int hvs_gather(hvs_index *idx, const int64_t *positions, int64_t n, float *out, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_gather: idx is NULL");
+    if (n <= 0) return 0;
+    HVS_REQUIRE(positions && out, "hvs_gather: NULL argument");
+    HVS_HIP(hipSetDevice(idx->device));
+    const int64_t *d_pos = positions;
+    float *d_out = out;
+    const size_t out_bytes = (size_t)n * idx->dim * 4;
+    if (!on_device) {
+        for (int64_t i = 0; i < n; i++)
+            HVS_REQUIRE(positions[i] >= 0 && positions[i] < idx->n, "hvs_gather: position %lld out of range", (long long)positions[i]);
+        void *stage = nullptr;
+        const size_t pos_off = (out_bytes + 255) & ~(size_t)255;
+        HVS_TRY(hvs_ws_get(idx, 3, pos_off + (size_t)n * 8, &stage));
+        d_out = (float *)stage;
+        d_pos = (const int64_t *)((char *)stage + pos_off);
+        HVS_HIP(hipMemcpyAsync((void *)d_pos, positions, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
+    }
+    const int g = grid_for(n * (int64_t)idx->dim);
+    if (idx->dtype == HVS_F32) gather_kernel<float><<<g, 256, 0, idx->stream>>>((const float *)idx->rows, d_pos, n, idx->dim, idx->ld, d_out);
+    else if (idx->dtype == HVS_F16) gather_kernel<__half><<<g, 256, 0, idx->stream>>>((const __half *)idx->rows, d_pos, n, idx->dim, idx->ld, d_out);
+    else gather_kernel<uint16_t><<<g, 256, 0, idx->stream>>>((const uint16_t *)idx->rows, d_pos, n, idx->dim, idx->ld, d_out);
+    HVS_HIP(hipGetLastError());
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    return 0;
+}
+
+extern "C" int hvs_profile_enable(hvs_index *idx, int on) {
+    HVS_REQUIRE(idx != nullptr, "hvs_profile_enable: idx is NULL");
+    idx->profiling = on != 0;
+    return 0;
+}
+
+extern "C" int hvs_profile_get(hvs_index *idx, int which, double *total_ms, int64_t *launches) {
+    HVS_REQUIRE(idx != nullptr, "hvs_profile_get: idx is NULL");
+    HVS_REQUIRE(which >= 0 && which < HVS_PROF_COUNT, "hvs_profile_get: unknown counter %d", which);
+    if (total_ms) *total_ms = idx->prof_ms[which];
+    if (launches) *launches = idx->prof_launches[which];
+    return 0;
+}
+
+extern "C" int hvs_profile_reset(hvs_index *idx) {
+    HVS_REQUIRE(idx != nullptr, "hvs_profile_reset: idx is NULL");
+    for (int i = 0; i < HVS_PROF_COUNT; i++) {
+        idx->prof_ms[i] = 0.0;
+        idx->prof_launches[i] = 0;
+    }
+    return 0;
+}
+
+extern "C" int hvs_timer_start(hvs_index *idx) {
+    HVS_REQUIRE(idx != nullptr, "hvs_timer_start: idx is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_HIP(hipEventRecord(idx->tm0, idx->stream));
+    return 0;
+}
+
+extern "C" int hvs_timer_stop(hvs_index *idx, double *elapsed_ms) {
+    HVS_REQUIRE(idx && elapsed_ms, "hvs_timer_stop: NULL argument");
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_HIP(hipEventRecord(idx->tm1, idx->stream));
+    HVS_HIP(hipEventSynchronize(idx->tm1));
+    float ms = 0.0f;
+    HVS_HIP(hipEventElapsedTime(&ms, idx->tm0, idx->tm1));
+    *elapsed_ms = ms;
+    return 0;
+}

@@ -1,0 +1,134 @@
+// Internal definitions shared by the translation units of libhvs.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/hvs.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+void hvs_set_error(const char *fmt, ...);
+
+#define HVS_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            hvs_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define HVS_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            hvs_set_error(__VA_ARGS__);   \
+            return 2;                     \
+        }                                 \
+    } while (0)
+
+#define HVS_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != 0) return rc_;  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// index object
+// ---------------------------------------------------------------------------
+struct hvs_workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct hvs_index {
+    int device = 0;
+    int dim = 0;        // logical dimension
+    int ld = 0;         // row pitch in elements (dim rounded up so a row is a whole number of 16-B chunks)
+    int dtype = HVS_F32;
+    int elem_size = 4;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    void *rows = nullptr;         // [cap, ld] elements, pad columns zero
+    float *inv_norm = nullptr;    // [cap] 1/|row| (+inf for a zero row, so distance becomes NaN)
+    int64_t *ids = nullptr;       // [cap] external ids
+    int32_t *groups = nullptr;    // [cap] group codes
+    uint32_t *deleted = nullptr;  // [ceil(cap/32)] bit set = row deleted; allocated on first delete
+    int64_t n_deleted = 0;
+    int64_t n = 0;
+    int64_t cap = 0;
+
+    hvs_workspace ws[4];  // scratch buffers reused across calls: 0 queries, 1/2 candidate lists, 3 staging
+
+    bool profiling = false;
+    double prof_ms[HVS_PROF_COUNT] = {0};
+    int64_t prof_launches[HVS_PROF_COUNT] = {0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // profiling pair
+    hipEvent_t tm0 = nullptr, tm1 = nullptr;  // user timer pair
+};
+
+int hvs_ws_get(hvs_index *idx, int slot, size_t bytes, void **out);
+
+// RAII-less profiling bracket: HVS_PROF_BEGIN(idx) ... launch ... HVS_PROF_END(idx, which)
+int hvs_prof_begin(hvs_index *idx);
+int hvs_prof_end(hvs_index *idx, int which);
+
+static inline int hvs_elem_size(int dtype) { return dtype == HVS_F32 ? 4 : 2; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#define HVS_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+// float -> uint32 whose unsigned order is the float order (NaN handled by the caller)
+__device__ __forceinline__ uint32_t hvs_ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float hvs_unord(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __uint_as_float(u);
+}
+__host__ __device__ __forceinline__ uint64_t hvs_make_key(uint32_t ord, uint32_t row) {
+    return ((uint64_t)ord << 32) | row;
+}
+
+// cosine distance from a dot product and the two inverse norms, pgvector's way:
+// clamp the similarity to [-1, 1] without destroying NaN, return 1 - sim.
+__device__ __forceinline__ float hvs_cos_dist(float dot, float inv_a, float inv_b) {
+    float sim = dot * inv_a * inv_b;
+    sim = sim > 1.0f ? 1.0f : (sim < -1.0f ? -1.0f : sim);
+    return 1.0f - sim;
+}
+
+__device__ __forceinline__ float hvs_bf16_to_float(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// round-to-nearest-even float -> bf16 bits; NaN stays NaN
+__device__ __forceinline__ uint16_t hvs_float_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ uint64_t hvs_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// smallest float >= d (so that "x < d" over floats x equals "x < result")
+static inline float hvs_ceil_to_float(double d) {
+    if (std::isnan(d)) return INFINITY;
+    float f = (float)d;
+    if ((double)f < d) f = std::nextafterf(f, INFINITY);
+    return f;
+}

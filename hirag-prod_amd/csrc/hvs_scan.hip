@@ -1,0 +1,683 @@
+// Bandwidth-bound exact scan (GEMV) with a fused wavefront-level top-k, the list-merge kernels and
+// the hvs_search / hvs_distances / hvs_merge_topk entry points.
+//
+// Data flow of one search:  rows stream HBM -> VGPRs exactly once (16 B per lane per load, one wave
+// per row, R rows in flight per wave); the query embeddings sit in LDS as fp32; every wave keeps a
+// sorted top-k list per query in LDS and only touches it when a row beats the list's current worst
+// (rare after the first few hundred rows), so the score vector is never written anywhere.  Each
+// block then folds its waves' lists into one and writes k keys; log_32(P) tiny merge launches reduce
+// the P block lists to the final answer.
+#include "hvs_internal.h"
+
+#define SCAN_THREADS 256
+#define SCAN_WAVES (SCAN_THREADS / 64)
+#define SCAN_R 4          // rows a wave has in flight
+#define MERGE_FAN 32      // lists merged by one wave of the merge kernel
+
+struct ScanParams {
+    const void *rows;
+    const float *inv_norm;
+    const int32_t *groups;
+    const uint32_t *mask;     // optional: bit set = row may be returned
+    const uint32_t *deleted;  // optional: bit set = row deleted
+    const float *queries;     // [nq_total, ld] fp32, pad columns zero
+    const float *q_inv;       // [nq_total]
+    int64_t row_begin, row_end;
+    int ld;       // row pitch in elements
+    int chunks;   // 16-byte chunks per row
+    int fold;     // embeddings folded by LEAST per output query
+    int nq_out;   // output queries in this launch (nq_out * fold <= NQ)
+    int k;
+    uint32_t thr_ord;  // ordered-uint image of the strict distance bound
+    int32_t group_filter;
+    uint64_t *partial;  // [nq_out, gridDim.x, k] keys (topk mode)
+    float *dist_out;    // [row_end - row_begin] (distance mode)
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 16-byte chunk -> floats ------------------------------------------------------------------
+template <int DT> struct Chunk;
+template <> struct Chunk<HVS_F32> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+};
+template <> struct Chunk<HVS_F16> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const __half2 h = *reinterpret_cast<const __half2 *>(&w[i]);
+            const float2 p = __half22float2(h);
+            f[2 * i] = p.x;
+            f[2 * i + 1] = p.y;
+        }
+    }
+};
+template <> struct Chunk<HVS_BF16> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+};
+
+// ---- wave-private sorted list in LDS ------------------------------------------------------------
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Insert a wave-uniform key into the ascending list L[0..cnt) of capacity k.  All 64 lanes call it.
+__device__ __forceinline__ void wave_insert(volatile uint64_t *L, int &cnt, int k, uint64_t key, int lane) {
+    int pos = 0;
+    for (int base = 0; base < cnt; base += 64) {
+        const int i = base + lane;
+        const bool lt = (i < cnt) && (L[i] < key);
+        pos += __popcll(__ballot(lt));
+    }
+    if (pos >= k) return;
+    const int newcnt = cnt < k ? cnt + 1 : k;
+    for (int base = ((newcnt - 1) >> 6) << 6; base >= ((pos >> 6) << 6); base -= 64) {
+        const int i = base + lane;
+        uint64_t v = 0;
+        bool w = false;
+        if (i > pos && i < newcnt) { v = L[i - 1]; w = true; }
+        else if (i == pos) { v = key; w = true; }
+        wave_fence();
+        if (w) L[i] = v;
+        wave_fence();
+    }
+    cnt = newcnt;
+}
+
+// Offer one candidate key per lane (HVS_KEY_EMPTY = none) to the list; tau = current admission bound.
+__device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k, uint64_t &tau, uint64_t thr_key,
+                                           uint64_t key, int lane) {
+    uint64_t pending = __ballot(key < tau);
+    while (pending) {
+        const int src = __ffsll((unsigned long long)pending) - 1;
+        pending &= pending - 1;
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)key, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
+        const uint64_t c = ((uint64_t)hi << 32) | lo;
+        if (c < tau) {
+            wave_insert(L, cnt, k, c, lane);
+            if (cnt == k) {
+                wave_fence();
+                tau = L[k - 1];
+            }
+        }
+    }
+    (void)thr_key;
+}
+
+// ---- the scan -----------------------------------------------------------------------------------
+template <int DT, int NQ, bool DISTONLY>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [NQ * ld] floats of queries, then per-wave lists [SCAN_WAVES][nq_out][k] keys, then counts
+    float *q_lds = reinterpret_cast<float *>(smem);
+    const int q_floats = NQ * p.ld;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_floats * 4 + 15) & ~(size_t)15));
+    int *cnts = reinterpret_cast<int *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nq_total = p.nq_out * p.fold;
+
+    for (int i = tid; i < q_floats; i += SCAN_THREADS) {
+        const int q = i / p.ld;
+        q_lds[i] = q < nq_total ? p.queries[i] : 0.0f;
+    }
+    __syncthreads();
+
+    float qinv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) qinv[q] = q < nq_total ? p.q_inv[q] : 0.0f;
+
+    volatile uint64_t *myL = lists + (size_t)wave * p.nq_out * p.k;
+    const uint64_t thr_key = (uint64_t)p.thr_ord << 32;
+    uint64_t tau[NQ];
+    int cnt[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { tau[q] = thr_key; cnt[q] = 0; }
+
+    const u32x4 *rows16 = reinterpret_cast<const u32x4 *>(p.rows);
+    const int64_t n_groups = (p.row_end - p.row_begin + SCAN_R - 1) / SCAN_R;
+    const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
+    const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
+    constexpr int EPC = Chunk<DT>::N;
+
+    for (int64_t g = gwave; g < n_groups; g += nwaves) {
+        const int64_t r0 = p.row_begin + g * SCAN_R;
+        bool live[SCAN_R];
+#pragma unroll
+        for (int r = 0; r < SCAN_R; r++) {
+            const int64_t row = r0 + r;
+            bool ok = row < p.row_end;
+            if (!DISTONLY && ok) {
+                if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+                if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+                if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+            }
+            live[r] = ok;
+        }
+        float acc[SCAN_R][NQ];
+#pragma unroll
+        for (int r = 0; r < SCAN_R; r++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[r][q] = 0.0f;
+
+#pragma unroll 2
+        for (int c = lane; c < p.chunks; c += 64) {
+            u32x4 v[SCAN_R];
+#pragma unroll
+            for (int r = 0; r < SCAN_R; r++) {
+                v[r] = (u32x4){0u, 0u, 0u, 0u};
+                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + (r0 + r) * p.chunks + c);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                float qf[8];
+                const float4 qa = *reinterpret_cast<const float4 *>(q_lds + q * p.ld + c * EPC);
+                qf[0] = qa.x; qf[1] = qa.y; qf[2] = qa.z; qf[3] = qa.w;
+                if (EPC == 8) {
+                    const float4 qb = *reinterpret_cast<const float4 *>(q_lds + q * p.ld + c * EPC + 4);
+                    qf[4] = qb.x; qf[5] = qb.y; qf[6] = qb.z; qf[7] = qb.w;
+                }
+#pragma unroll
+                for (int r = 0; r < SCAN_R; r++) {
+                    float f[8];
+                    Chunk<DT>::widen(v[r], f);
+#pragma unroll
+                    for (int e = 0; e < EPC; e++) acc[r][q] = fmaf(f[e], qf[e], acc[r][q]);
+                }
+            }
+        }
+        // all-lanes butterfly: every lane ends with the full dot products
+#pragma unroll
+        for (int r = 0; r < SCAN_R; r++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                float s = acc[r][q];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                acc[r][q] = s;
+            }
+#pragma unroll
+        for (int r = 0; r < SCAN_R; r++) {
+            const int64_t row = r0 + r;
+            if (!live[r]) continue;  // wave-uniform
+            const float inv = p.inv_norm[row];
+#pragma unroll
+            for (int qo = 0; qo < NQ; qo++) {
+                if (qo >= p.nq_out) break;
+                float d = __builtin_nanf("");
+                for (int j = 0; j < p.fold; j++) {
+                    const int q = qo * p.fold + j;
+                    float dq = 0.0f, iq = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < NQ; t++) if (t == q) { dq = acc[r][t]; iq = qinv[t]; }
+                    d = fminf(d, hvs_cos_dist(dq, inv, iq));  // fminf drops a NaN operand: LEAST semantics
+                }
+                if (DISTONLY) {
+                    if (lane == 0) p.dist_out[row - p.row_begin] = d;
+                } else {
+                    const uint64_t key = (d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
+                    if (key < tau[qo]) {  // wave-uniform
+                        wave_insert(myL + (size_t)qo * p.k, cnt[qo], p.k, key, lane);
+                        if (cnt[qo] == p.k) {
+                            wave_fence();
+                            tau[qo] = myL[(size_t)qo * p.k + p.k - 1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (DISTONLY) return;
+
+    // fold the block's wave lists into wave 0's, then publish k keys per query
+#pragma unroll
+    for (int qo = 0; qo < NQ; qo++)
+        if (qo < p.nq_out && lane == 0) cnts[wave * NQ + qo] = cnt[qo];
+    __syncthreads();
+    if (wave != 0) return;
+    for (int qo = 0; qo < p.nq_out; qo++) {
+        int c0 = 0;
+        uint64_t t0 = thr_key;
+#pragma unroll
+        for (int t = 0; t < NQ; t++) if (t == qo) { c0 = cnt[t]; t0 = tau[t]; }
+        volatile uint64_t *L0 = myL + (size_t)qo * p.k;
+        for (int w = 1; w < SCAN_WAVES; w++) {
+            const volatile uint64_t *Lw = lists + ((size_t)w * p.nq_out + qo) * p.k;
+            const int cw = cnts[w * NQ + qo];
+            for (int base = 0; base < cw; base += 64) {
+                const int i = base + lane;
+                const uint64_t key = i < cw ? Lw[i] : HVS_KEY_EMPTY;
+                wave_offer(L0, c0, p.k, t0, thr_key, key, lane);
+            }
+        }
+        wave_fence();
+        uint64_t *out = p.partial + ((size_t)qo * gridDim.x + blockIdx.x) * p.k;
+        for (int i = lane; i < p.k; i += 64) out[i] = i < c0 ? L0[i] : HVS_KEY_EMPTY;
+    }
+}
+
+// ---- list merging -------------------------------------------------------------------------------
+// in: [nq, P, k] ascending keys padded with HVS_KEY_EMPTY.  One wave merges MERGE_FAN consecutive lists.
+// FINAL = false: out keys [nq, P2, k].  FINAL = true (P2 == 1): distances / ids / counts.
+template <bool FINAL>
+__global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restrict__ in, int P, int k, uint64_t *out_keys,
+                                                          const int64_t *__restrict__ ids, float *out_dist,
+                                                          int64_t *out_ids, int32_t *out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile uint64_t *L = reinterpret_cast<volatile uint64_t *>(smem);
+    const int lane = threadIdx.x;
+    const int grp = blockIdx.x;
+    const int q = blockIdx.y;
+    const int P2 = gridDim.x;
+    const int first = grp * MERGE_FAN;
+    const int nl = (P - first) < MERGE_FAN ? (P - first) : MERGE_FAN;
+    const uint64_t *src = in + ((size_t)q * P + first) * k;
+    const int64_t total = (int64_t)nl * k;
+    int cnt = 0;
+    uint64_t tau = HVS_KEY_EMPTY;
+    for (int64_t base = 0; base < total; base += 64) {
+        const int64_t i = base + lane;
+        const uint64_t key = i < total ? src[i] : HVS_KEY_EMPTY;
+        wave_offer(L, cnt, k, tau, 0, key, lane);
+    }
+    wave_fence();
+    if (!FINAL) {
+        uint64_t *o = out_keys + ((size_t)q * P2 + grp) * k;
+        for (int i = lane; i < k; i += 64) o[i] = i < cnt ? L[i] : HVS_KEY_EMPTY;
+    } else {
+        for (int i = lane; i < k; i += 64) {
+            float d = __builtin_inff();
+            int64_t id = -1;
+            if (i < cnt) {
+                const uint64_t key = L[i];
+                d = hvs_unord((uint32_t)(key >> 32));
+                const uint32_t row = (uint32_t)key;
+                id = ids ? ids[row] : (int64_t)row;
+            }
+            out_dist[(size_t)q * k + i] = d;
+            out_ids[(size_t)q * k + i] = id;
+        }
+        if (lane == 0) out_count[q] = cnt;
+    }
+}
+
+// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys
+int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
+                     int64_t *d_ids, int32_t *d_count) {
+    const size_t lds = (size_t)k * 8;
+    uint64_t *in = bufA, *out = bufB;
+    while (P > MERGE_FAN) {
+        const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
+        merge_lists_kernel<false><<<dim3(P2, nq), 64, lds, idx->stream>>>(in, P, k, out, nullptr, nullptr, nullptr, nullptr);
+        HVS_HIP(hipGetLastError());
+        uint64_t *t = in; in = out; out = t;
+        P = P2;
+    }
+    merge_lists_kernel<true><<<dim3(1, nq), 64, lds, idx->stream>>>(in, P, k, nullptr, idx->ids, d_dist, d_ids, d_count);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- query preparation --------------------------------------------------------------------------
+// dst[q][c] = query value rounded to the column type (binding a parameter with the column's type), pad 0;
+// q_inv[q] = 1/|dst[q]|.  One wave per query.
+__global__ void prep_queries_kernel(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ q_inv,
+                                    int nq, int dim, int ld, int dtype) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    float s = 0.0f;
+    for (int c = lane; c < ld; c += 64) {
+        float v = 0.0f;
+        if (c < dim) {
+            v = src[(size_t)q * dim + c];
+            if (dtype == HVS_F16) v = __half2float(__float2half_rn(v));
+            else if (dtype == HVS_BF16) v = hvs_bf16_to_float(hvs_float_to_bf16(v));
+        }
+        dst[(size_t)q * ld + c] = v;
+        s = fmaf(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) q_inv[q] = (float)(1.0 / sqrt((double)s));
+}
+
+int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int on_device, float **d_q, float **d_qinv) {
+    const size_t qbytes = (size_t)nq_total * idx->ld * 4;
+    const size_t inv_off = (qbytes + 255) & ~(size_t)255;
+    const size_t raw_off = (inv_off + (size_t)nq_total * 4 + 255) & ~(size_t)255;
+    const size_t raw_bytes = on_device ? 0 : (size_t)nq_total * idx->dim * 4;
+    void *ws = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 0, raw_off + raw_bytes, &ws));
+    const float *src = queries;
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync((char *)ws + raw_off, queries, raw_bytes, hipMemcpyHostToDevice, idx->stream));
+        src = (const float *)((char *)ws + raw_off);
+    }
+    *d_q = (float *)ws;
+    *d_qinv = (float *)((char *)ws + inv_off);
+    prep_queries_kernel<<<(nq_total + 3) / 4, 256, 0, idx->stream>>>(src, *d_q, *d_qinv, nq_total, idx->dim, idx->ld, idx->dtype);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------
+template <int DT, bool DISTONLY>
+static int launch_scan_nq(int NQ, int grid, size_t lds, hipStream_t s, const ScanParams &p) {
+#define HVS_SCAN_CASE(N)                                                                                      \
+    case N:                                                                                                   \
+        if (lds > 48 * 1024)                                                                                  \
+            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DT, N, DISTONLY>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        scan_kernel<DT, N, DISTONLY><<<grid, SCAN_THREADS, lds, s>>>(p);                                     \
+        break;
+    switch (NQ) {
+        HVS_SCAN_CASE(1)
+        HVS_SCAN_CASE(2)
+        HVS_SCAN_CASE(4)
+        HVS_SCAN_CASE(8)
+    default: hvs_set_error("scan: unsupported NQ %d", NQ); return 2;
+    }
+#undef HVS_SCAN_CASE
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+template <bool DISTONLY>
+static int launch_scan(int dtype, int NQ, int grid, size_t lds, hipStream_t s, const ScanParams &p) {
+    if (dtype == HVS_F32) return launch_scan_nq<HVS_F32, DISTONLY>(NQ, grid, lds, s, p);
+    if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, DISTONLY>(NQ, grid, lds, s, p);
+    return launch_scan_nq<HVS_BF16, DISTONLY>(NQ, grid, lds, s, p);
+}
+
+static inline int round_nq(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
+
+static size_t scan_lds_bytes(int NQ, int ld, int nq_out, int k) {
+    size_t b = ((size_t)NQ * ld * 4 + 15) & ~(size_t)15;
+    b += (size_t)SCAN_WAVES * nq_out * k * 8;
+    b += (size_t)SCAN_WAVES * NQ * 4;
+    return b;
+}
+
+static const size_t LDS_LIMIT = 160 * 1024;
+
+// Run the scan path for out-queries [0, nq) (already prepared on device).  Results to device buffers.
+int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
+                    int64_t *d_ids, int32_t *d_count) {
+    // out-queries per pass: as many as fit 8 dot products and the LDS budget
+    int per_pass = 8 / fold;
+    if (per_pass < 1) per_pass = 1;
+    if (per_pass > nq) per_pass = nq;
+    while (per_pass > 1 && scan_lds_bytes(round_nq(per_pass * fold), idx->ld, per_pass, k) > LDS_LIMIT / 2) per_pass--;
+    const int NQ = round_nq(per_pass * fold);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, per_pass, k);
+    HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_search: dim %d with fold %d and k %d needs %zu bytes of LDS (limit %zu)", idx->dim, fold, k, lds, LDS_LIMIT);
+
+    const int64_t n_rows = row_end - row_begin;
+    const int64_t row_groups = (n_rows + SCAN_R - 1) / SCAN_R;
+    int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
+    int grid = 256 * 4;
+    if (want_blocks < grid) grid = (int)(want_blocks < 1 ? 1 : want_blocks);
+    const int P = grid;
+    const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
+    void *bufA = nullptr, *bufB = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 1, (size_t)per_pass * P * k * 8, &bufA));
+    HVS_TRY(hvs_ws_get(idx, 2, (size_t)per_pass * P2 * k * 8, &bufB));
+
+    ScanParams p;
+    p.rows = idx->rows;
+    p.inv_norm = idx->inv_norm;
+    p.groups = idx->groups;
+    p.mask = d_mask;
+    p.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    p.ld = idx->ld;
+    p.chunks = idx->ld * idx->elem_size / 16;
+    p.fold = fold;
+    p.k = k;
+    p.thr_ord = 0;
+    {
+        // ordered image of thr, computed like the device's hvs_ord
+        uint32_t u;
+        memcpy(&u, &thr, 4);
+        p.thr_ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    p.group_filter = group_filter;
+    p.partial = (uint64_t *)bufA;
+    p.dist_out = nullptr;
+
+    for (int q0 = 0; q0 < nq; q0 += per_pass) {
+        const int nqo = (nq - q0 < per_pass) ? nq - q0 : per_pass;
+        p.queries = d_q + (size_t)q0 * fold * idx->ld;
+        p.q_inv = d_qinv + (size_t)q0 * fold;
+        p.nq_out = nqo;
+        const size_t lds_pass = scan_lds_bytes(NQ, idx->ld, nqo, k);
+        HVS_TRY(hvs_prof_begin(idx));
+        HVS_TRY(launch_scan<false>(idx->dtype, NQ, grid, lds_pass, idx->stream, p));
+        HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
+        HVS_TRY(hvs_prof_begin(idx));
+        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nqo, P, k, d_dist + (size_t)q0 * k,
+                                 d_ids + (size_t)q0 * k, d_count + q0));
+        HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+    }
+    return 0;
+}
+
+int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
+                    int64_t *d_ids, int32_t *d_count);
+bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k);
+
+// ---- C ABI --------------------------------------------------------------------------------------
+extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter,
+                          const uint32_t *row_mask, double max_distance, int64_t row_begin, int64_t row_end,
+                          float *out_dist, int64_t *out_ids, int32_t *out_count, int on_device, int algo) {
+    HVS_REQUIRE(idx != nullptr, "hvs_search: idx is NULL");
+    HVS_REQUIRE(nq >= 0, "hvs_search: negative query count");
+    if (nq == 0) return 0;
+    HVS_REQUIRE(queries && out_dist && out_ids && out_count, "hvs_search: NULL argument");
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_search: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_search: k %d not in [1, %d]", k, HVS_MAX_K);
+    HVS_REQUIRE(algo == HVS_ALGO_AUTO || algo == HVS_ALGO_SCAN || algo == HVS_ALGO_MFMA, "hvs_search: unknown algo %d", algo);
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_begin > row_end) row_begin = row_end;
+    HVS_HIP(hipSetDevice(idx->device));
+    const float thr = hvs_ceil_to_float(max_distance);
+    const int nq_total = nq * fold;
+
+    float *d_q = nullptr, *d_qinv = nullptr;
+    HVS_TRY(hvs_prepare_queries(idx, queries, nq_total, on_device, &d_q, &d_qinv));
+
+    float *d_dist = out_dist;
+    int64_t *d_ids = out_ids;
+    int32_t *d_count = out_count;
+    const uint32_t *d_mask = row_mask;
+    const size_t dist_bytes = (size_t)nq * k * 4, ids_bytes = (size_t)nq * k * 8, cnt_bytes = (size_t)nq * 4;
+    const size_t mask_bytes = row_mask ? (size_t)((idx->n + 31) / 32) * 4 : 0;
+    if (!on_device) {
+        void *stage = nullptr;
+        const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
+        const size_t o_cnt = (o_ids + ids_bytes + 255) & ~(size_t)255;
+        const size_t o_mask = (o_cnt + cnt_bytes + 255) & ~(size_t)255;
+        HVS_TRY(hvs_ws_get(idx, 3, o_mask + mask_bytes, &stage));
+        d_dist = (float *)stage;
+        d_ids = (int64_t *)((char *)stage + o_ids);
+        d_count = (int32_t *)((char *)stage + o_cnt);
+        if (row_mask) {
+            HVS_HIP(hipMemcpyAsync((char *)stage + o_mask, row_mask, mask_bytes, hipMemcpyHostToDevice, idx->stream));
+            d_mask = (const uint32_t *)((char *)stage + o_mask);
+        }
+    }
+
+    bool use_mfma = false;
+    if (algo == HVS_ALGO_MFMA) {
+        HVS_REQUIRE(hvs_mfma_supported(idx, nq, fold, k), "hvs_search: the MFMA path does not support this shape (dtype %d, dim %d, fold %d, k %d)", idx->dtype, idx->dim, fold, k);
+        use_mfma = true;
+    } else if (algo == HVS_ALGO_AUTO) {
+        use_mfma = nq_total >= 32 && hvs_mfma_supported(idx, nq, fold, k);
+    }
+    if (row_end == row_begin) {
+        // empty range: counts 0, +inf / -1 entries
+        use_mfma = false;
+    }
+    if (use_mfma)
+        HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
+    else
+        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
+
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync(out_dist, d_dist, dist_bytes, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipMemcpyAsync(out_ids, d_ids, ids_bytes, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipMemcpyAsync(out_count, d_count, cnt_bytes, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    return 0;
+}
+
+extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int64_t row_begin, int64_t row_end,
+                             float *out, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_distances: idx is NULL");
+    HVS_REQUIRE(queries && out, "hvs_distances: NULL argument");
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_distances: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_begin >= row_end) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    float *d_q = nullptr, *d_qinv = nullptr;
+    HVS_TRY(hvs_prepare_queries(idx, queries, fold, on_device, &d_q, &d_qinv));
+    const int64_t n_rows = row_end - row_begin;
+    float *d_out = out;
+    if (!on_device) {
+        void *stage = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 3, (size_t)n_rows * 4, &stage));
+        d_out = (float *)stage;
+    }
+    const int NQ = round_nq(fold);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, 1, 1);
+    HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_distances: dim %d with fold %d needs %zu bytes of LDS", idx->dim, fold, lds);
+    ScanParams p;
+    memset(&p, 0, sizeof(p));
+    p.rows = idx->rows;
+    p.inv_norm = idx->inv_norm;
+    p.queries = d_q;
+    p.q_inv = d_qinv;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    p.ld = idx->ld;
+    p.chunks = idx->ld * idx->elem_size / 16;
+    p.fold = fold;
+    p.nq_out = 1;
+    p.k = 1;
+    p.group_filter = -1;
+    p.dist_out = d_out;
+    const int64_t row_groups = (n_rows + SCAN_R - 1) / SCAN_R;
+    int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
+    int grid = 256 * 4;
+    if (want_blocks < grid) grid = (int)want_blocks;
+    HVS_TRY(hvs_prof_begin(idx));
+    HVS_TRY(launch_scan<true>(idx->dtype, NQ, grid, lds, idx->stream, p));
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync(out, d_out, (size_t)n_rows * 4, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    return 0;
+}
+
+// ---- cross-GPU merge ----------------------------------------------------------------------------
+// (dist, id) lists -> keys are not usable here (ids are 64-bit), so this kernel orders pairs directly.
+// One wave per query; candidates = P*k pairs; selection by rank counting in chunks through LDS.
+__global__ __launch_bounds__(64) void merge_pairs_kernel(const float *__restrict__ in_dist, const int64_t *__restrict__ in_ids,
+                                                          const int32_t *__restrict__ in_count, int P, int k,
+                                                          float *out_dist, int64_t *out_ids, int32_t *out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: sorted list of k (dist, id) pairs
+    volatile float *Ld = reinterpret_cast<volatile float *>(smem);
+    volatile int64_t *Li = reinterpret_cast<volatile int64_t *>(smem + (((size_t)k * 4 + 15) & ~(size_t)15));
+    const int lane = threadIdx.x;
+    const int q = blockIdx.x;
+    int cnt = 0;
+    for (int pl = 0; pl < P; pl++) {
+        const int c = in_count[(size_t)q * P + pl];
+        const float *sd = in_dist + ((size_t)q * P + pl) * k;
+        const int64_t *si = in_ids + ((size_t)q * P + pl) * k;
+        for (int base = 0; base < c; base += 64) {
+            const int i = base + lane;
+            const bool have = i < c;
+            const float d = have ? sd[i] : __builtin_inff();
+            const int64_t id = have ? si[i] : 0x7FFFFFFFFFFFFFFFll;
+            uint64_t pending = __ballot(have);
+            while (pending) {
+                const int src = __ffsll((unsigned long long)pending) - 1;
+                pending &= pending - 1;
+                const float cd = __shfl(d, src);
+                const int64_t cid = ((int64_t)__shfl((int)(id >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)id, src);
+                // position = number of entries ordered before (cd, cid)
+                int pos = 0;
+                for (int b2 = 0; b2 < cnt; b2 += 64) {
+                    const int j = b2 + lane;
+                    bool lt = false;
+                    if (j < cnt) {
+                        const float ld = Ld[j];
+                        const int64_t li = Li[j];
+                        lt = ld < cd || (ld == cd && li < cid);
+                    }
+                    pos += __popcll(__ballot(lt));
+                }
+                if (pos >= k) continue;
+                const int newcnt = cnt < k ? cnt + 1 : k;
+                for (int b2 = ((newcnt - 1) >> 6) << 6; b2 >= ((pos >> 6) << 6); b2 -= 64) {
+                    const int j = b2 + lane;
+                    float vd = 0.0f;
+                    int64_t vi = 0;
+                    bool w = false;
+                    if (j > pos && j < newcnt) { vd = Ld[j - 1]; vi = Li[j - 1]; w = true; }
+                    else if (j == pos) { vd = cd; vi = cid; w = true; }
+                    wave_fence();
+                    if (w) { Ld[j] = vd; Li[j] = vi; }
+                    wave_fence();
+                }
+                cnt = newcnt;
+            }
+        }
+    }
+    wave_fence();
+    for (int i = lane; i < k; i += 64) {
+        out_dist[(size_t)q * k + i] = i < cnt ? Ld[i] : __builtin_inff();
+        out_ids[(size_t)q * k + i] = i < cnt ? Li[i] : -1;
+    }
+    if (lane == 0) out_count[q] = cnt;
+}
+
+extern "C" int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int64_t *in_ids,
+                              const int32_t *in_count, int nq, int P, int k, float *out_dist, int64_t *out_ids,
+                              int32_t *out_count) {
+    HVS_REQUIRE(nq >= 0 && P >= 1, "hvs_merge_topk: bad nq/P");
+    if (nq == 0) return 0;
+    HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_merge_topk: k %d not in [1, %d]", k, HVS_MAX_K);
+    HVS_REQUIRE(in_dist && in_ids && in_count && out_dist && out_ids && out_count, "hvs_merge_topk: NULL argument");
+    HVS_HIP(hipSetDevice(device_id));
+    const size_t lds = (((size_t)k * 4 + 15) & ~(size_t)15) + (size_t)k * 8;
+    merge_pairs_kernel<<<nq, 64, lds, (hipStream_t)stream>>>(in_dist, in_ids, in_count, P, k, out_dist, out_ids, out_count);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}

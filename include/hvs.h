@@ -1,0 +1,175 @@
+/*
+ * hvs -- HIP vector store: C ABI of the MI355X (gfx950) dense-retrieval path.
+ *
+ * The reference (htlyu/hirag-prod) has no native boundary for this path: it
+ * sends SQL to PostgreSQL and the pgvector extension computes
+ * "vector <=> query ... ORDER BY distance LIMIT k" server-side.  Each entry
+ * point below names the reference interface whose work it takes over; the
+ * Python host side (hirag-prod_amd/store.py) binds them with ctypes exactly
+ * as INTEGRATION.md shows.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message
+ *     for the calling thread's last failure is hvs_last_error();
+ *   - no C++ exceptions, torch types or HIP types cross the boundary (streams
+ *     travel as void*);
+ *   - the caller owns every buffer it passes; "on_device" says whether the
+ *     caller's buffers are host memory (0) or memory of the index's GPU (1);
+ *   - an hvs_index owns its device memory and works on one HIP stream; calls
+ *     on one index must not overlap (the Python side serialises them);
+ *   - functions return after their work on the stream has been submitted when
+ *     on_device = 1 (call hvs_sync before reading results on another stream)
+ *     and after it has completed when on_device = 0.
+ */
+#ifndef HVS_H
+#define HVS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hvs_index hvs_index;
+
+/* element type of the stored rows; schema/vector_config.py:8-11 (HALFVEC = fp16, VECTOR = fp32) */
+enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
+
+/* search algorithm selector */
+enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2 };
+
+/* counters readable through hvs_profile_get */
+enum { HVS_PROF_SCAN = 0, HVS_PROF_MFMA_SEARCH = 1, HVS_PROF_KMEANS_ASSIGN = 2, HVS_PROF_KMEANS_UPDATE = 3,
+       HVS_PROF_MERGE = 4, HVS_PROF_COUNT = 5 };
+
+#define HVS_MAX_K 1024       /* largest top-k a search accepts */
+#define HVS_MAX_FOLD 8       /* largest number of query embeddings folded by LEAST */
+
+const char *hvs_last_error(void);
+int hvs_version(void);
+int hvs_device_count(int *out);
+
+/*
+ * Table life cycle.  Replaces PGVector._init_vdb / create_all
+ * (src/hirag_prod/storage/pgvector.py:704-726): one index per embedded table
+ * (Chunks, Items, Triplets).  stream = a hipStream_t to work on, or NULL for a
+ * stream the index creates itself.
+ */
+int hvs_index_create(hvs_index **out, int device_id, int dim, int dtype, void *stream);
+int hvs_index_destroy(hvs_index *idx);
+int hvs_index_reserve(hvs_index *idx, int64_t capacity_rows);
+int hvs_index_size(hvs_index *idx, int64_t *out_rows);
+int hvs_index_info(hvs_index *idx, int *dim, int *dtype, int *device_id, int64_t *capacity_rows);
+int hvs_sync(hvs_index *idx);
+
+/*
+ * Append rows.  Replaces the INSERT of PGVector.upsert_texts
+ * (pgvector.py:128-172): rows arrive as src_dtype (HVS_F32 or the index's own
+ * type) and are rounded to the column type on the way in, as storing into
+ * HALFVEC does; the inverse L2 norm of every stored row is computed once here.
+ * ids: external 64-bit id per row, or NULL for "first_id + position".
+ * group_codes: one int32 per row standing for (workspaceId, knowledgeBaseId)
+ * (the WHERE workspaceId = .. AND knowledgeBaseId = .. of pgvector.py:577-580),
+ * or NULL for group 0.
+ */
+int hvs_index_add(hvs_index *idx, const void *rows, int src_dtype, int64_t n,
+                  const int64_t *ids, const int32_t *group_codes, int on_device);
+
+/* Overwrite stored rows in place (positions are row positions, not ids). */
+int hvs_index_update(hvs_index *idx, const int64_t *positions, const void *rows, int src_dtype,
+                     int64_t n, int on_device);
+
+/*
+ * Mark rows deleted / live.  Replaces DELETE ... WHERE of PGVector.clean_table
+ * (pgvector.py:452-473) for the vector side: a deleted row is never returned.
+ */
+int hvs_index_set_deleted(hvs_index *idx, const int64_t *positions, int64_t n, int deleted);
+
+/*
+ * Fill the index with n synthetic rows generated on the device: row r (global
+ * number first_global_row + r), column c is ((sum of the four 16-bit fields of
+ * splitmix64((r*dim+c) ^ splitmix64(seed))) - 131070) * (1/37837), an
+ * approximately N(0,1) value any host can regenerate bit for bit.  ids are the
+ * global row numbers; group code = global row number mod n_groups.
+ * (Benchmark and parity-at-scale support; no reference counterpart.)
+ */
+int hvs_index_fill_synthetic(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row,
+                             int32_t n_groups);
+
+/*
+ * Exact cosine top-k.  Replaces the statement PGVector.query builds and
+ * PostgreSQL + pgvector execute (pgvector.py:561-585):
+ *     distance = LEAST_{j < fold}(vector <=> q[i*fold + j])
+ *     WHERE [group = group_filter] AND [row_mask bit set] AND distance < max_distance
+ *     ORDER BY distance ASC LIMIT k
+ * queries: float [nq * fold, dim]; query i of the nq results folds embeddings
+ * i*fold .. i*fold+fold-1.  group_filter < 0 = no group filter.  row_mask:
+ * optional bitmask, bit (r & 31) of word r >> 5 set = row r may be returned
+ * (the uri IN (...) / private = ... filters, evaluated by the host).
+ * max_distance: strict upper bound, +inf for none.  [row_begin, row_end):
+ * row positions to scan (row_end < 0 = all).
+ * Outputs, caller-allocated: out_dist float [nq, k], out_ids int64 [nq, k]
+ * (sorted by distance, ties by lower row position), out_count int32 [nq]
+ * (entries beyond the count are +inf / -1).  NaN distances (zero-norm row or
+ * query) are never returned.
+ */
+int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k,
+               int32_t group_filter, const uint32_t *row_mask, double max_distance,
+               int64_t row_begin, int64_t row_end,
+               float *out_dist, int64_t *out_ids, int32_t *out_count,
+               int on_device, int algo);
+
+/*
+ * Full distance column.  Replaces the projected LEAST(Item.vector <=> e_i)
+ * column of cross-language search
+ * (src/hirag_prod/cross_language_search/search_service.py:100-113):
+ * out[r - row_begin] = LEAST_j(distance(row r, q_j)) for every row of the
+ * range, NaN where undefined; no filtering, no ordering.
+ */
+int hvs_distances(hvs_index *idx, const float *queries, int fold,
+                  int64_t row_begin, int64_t row_end, float *out, int on_device);
+
+/*
+ * Fetch stored vectors by row position, widened to float.  Replaces selecting
+ * the "vector" column in PGVector.query_by_keys (pgvector.py:606-660) as used
+ * by QueryService.query_chunk_embeddings (storage/query_service.py:194-224).
+ */
+int hvs_gather(hvs_index *idx, const int64_t *positions, int64_t n, float *out, int on_device);
+
+/*
+ * Merge P sorted candidate lists per query into one top-k (the step after the
+ * all-gather when the corpus is row-sharded over GPUs).  Device buffers on
+ * device_id: in_dist float [nq, P, k], in_ids int64 [nq, P, k], in_count int32
+ * [nq, P]; outputs as hvs_search.  Ordering: distance, then lower id.
+ * No reference counterpart (the reference is single-node).
+ */
+int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int64_t *in_ids,
+                   const int32_t *in_count, int nq, int P, int k,
+                   float *out_dist, int64_t *out_ids, int32_t *out_count);
+
+/*
+ * One k-means E-step plus the partial sums of the M-step over the index's rows
+ * (index dtype must be HVS_F32): assign[r] = argmin_j |x_r - c_j|^2 (lowest j
+ * on ties); sums[j] += x_r, counts[j] += 1.  out_sums / out_counts may be NULL
+ * (assignment only); they are overwritten, not accumulated.  Deleted rows get
+ * assignment -1 and add nothing.  No reference counterpart (the reference's
+ * only clustering is ward agglomeration of <= 10 vectors,
+ * src/hirag_prod/cluster/hierachical_cluster.py:42-46); the sums are what a
+ * multi-GPU build all-reduces.
+ */
+int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids,
+                      int32_t *out_assign, float *out_sums, int64_t *out_counts, int on_device);
+
+/* Per-kernel device time, measured with HIP events on the index's stream. */
+int hvs_profile_enable(hvs_index *idx, int on);
+int hvs_profile_get(hvs_index *idx, int which, double *total_ms, int64_t *launches);
+int hvs_profile_reset(hvs_index *idx);
+
+/* Generic timer on the index's stream (HIP events): start, later stop -> elapsed ms. */
+int hvs_timer_start(hvs_index *idx);
+int hvs_timer_stop(hvs_index *idx, double *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVS_H */

@@ -1,0 +1,61 @@
+"""Shared parity checks: the HIP path against the float64 oracle.
+
+Bar (stated by the task for this path): returned ids identical to the oracle's
+except where two distances differ by <= 1e-6 (a tie at fp32 resolution); scores
+within 1e-5 * max(1, |s|) for fp32 and fp16 storage (fp16 products are exact in
+fp32, so the same bound holds); the same bound is used for bf16 storage because
+the query is rounded to the column type first and every product is again exact.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import pgvector_oracle as po
+
+TIE = 1e-6
+SCORE_TOL = 1e-5
+
+
+def full_distances(rows, q_embs, storage):
+    rows_s = po.round_storage(rows, storage)
+    q_s = po.round_storage(np.atleast_2d(q_embs), storage)
+    d = np.stack([po.cosine_distance(rows_s, q_s[i]) for i in range(q_s.shape[0])])
+    return po.least_fold(d)
+
+
+def check_topk(gpu_dist, gpu_ids, gpu_cnt, full, k, threshold=None, keep=None, id_of_row=None, label=""):
+    """``full``: float64 distance of every row (NaN allowed).  gpu_*: one query's outputs."""
+    exp_idx, exp_dist = po.order_by_limit(full, keep, threshold, k)
+    cnt = int(gpu_cnt)
+    if cnt != len(exp_idx):
+        # only legal when a row sits within TIE of the threshold
+        assert threshold is not None, f"{label}: count {cnt} != {len(exp_idx)}"
+        ok = np.ones_like(full, dtype=bool) if keep is None else np.asarray(keep, bool)
+        near = np.nonzero(ok & (np.abs(full - threshold) <= TIE))[0]
+        assert abs(cnt - len(exp_idx)) <= len(near), f"{label}: count {cnt} != {len(exp_idx)} (no row near the threshold)"
+        return
+    gd = np.asarray(gpu_dist[:cnt], dtype=np.float64)
+    gi = np.asarray(gpu_ids[:cnt], dtype=np.int64)
+    if id_of_row is not None:
+        row_of_id = {int(v): i for i, v in enumerate(id_of_row)}
+        gi_rows = np.array([row_of_id[int(v)] for v in gi], dtype=np.int64)
+    else:
+        gi_rows = gi
+    assert len(set(gi_rows.tolist())) == cnt, f"{label}: duplicate ids returned"
+    tol = SCORE_TOL * np.maximum(1.0, np.abs(exp_dist))
+    assert np.all(np.abs(gd - exp_dist) <= tol), f"{label}: scores differ: {gd} vs {exp_dist}"
+    assert np.all(np.diff(gd) >= 0), f"{label}: not sorted"
+    for pos, (g, e) in enumerate(zip(gi_rows, exp_idx)):
+        if g != e:
+            assert abs(full[g] - exp_dist[pos]) <= TIE, (
+                f"{label}: rank {pos}: got row {g} (d={full[g]!r}) expected row {e} (d={exp_dist[pos]!r})"
+            )
+            if keep is not None:
+                assert keep[g], f"{label}: filtered row {g} returned"
+    # entries past the count are padding
+    assert np.all(np.isinf(gpu_dist[cnt:])) and np.all(np.asarray(gpu_ids[cnt:]) == -1), f"{label}: bad padding"
+
+
+def bf16_bits(x32: np.ndarray) -> np.ndarray:
+    return (po.bf16_round(x32).view(np.uint32) >> 16).astype(np.uint16)

@@ -1,0 +1,201 @@
+"""GPU tier: the HIP scan path (through the C ABI) against the oracle."""
+
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pgv_scan, pgvector_oracle as po
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hvs():
+    import hirag_prod_amd
+
+    assert hirag_prod_amd.device_count() >= 1, "no GPU visible to libhvs"
+    return hirag_prod_amd
+
+
+def _mk(hvs, rows, dtype, groups=None):
+    idx = hvs.HvsIndex(rows.shape[1], dtype)
+    idx.add(rows, group_codes=groups)
+    assert len(idx) == rows.shape[0]
+    return idx
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("n,d", [(3000, 8), (2500, 100), (4096, 768), (3001, 1536)])
+def test_scan_topk_matches_oracle(hvs, dtype, n, d):
+    rng = np.random.default_rng(n + d)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[5] = 0.0  # zero-norm row -> NaN distance, never returned
+    rows[9] = rows[4]  # exact tie
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    idx = _mk(hvs, rows, dtype)
+    for k in (1, 10, 100):
+        dist, ids, cnt = idx.search(q, k=k, algo="scan")
+        for i in range(q.shape[0]):
+            full = parity.full_distances(rows, q[i], dtype)
+            parity.check_topk(dist[i], ids[i], cnt[i], full, k, label=f"{dtype} n={n} d={d} k={k} q={i}")
+            assert 5 not in ids[i][: cnt[i]]
+    # fold = 3 (LEAST over three embeddings), threshold 0.8 as the reference's default
+    dist, ids, cnt = idx.search(q, k=10, fold=3, max_distance=0.95, algo="scan")
+    for i in range(2):
+        full = parity.full_distances(rows, q[3 * i : 3 * i + 3], dtype)
+        parity.check_topk(dist[i], ids[i], cnt[i], full, 10, threshold=0.95, label=f"fold3 {dtype} q={i}")
+    idx.close()
+
+
+def test_filters_threshold_deleted(hvs):
+    rng = np.random.default_rng(11)
+    n, d = 6000, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    groups = (np.arange(n) % 5).astype(np.int32)
+    q = rng.standard_normal((2, d)).astype(np.float32)
+    idx = _mk(hvs, rows, "f32", groups)
+    keep_bits = rng.random(n) < 0.3
+    mask = np.zeros((n + 31) // 32, dtype=np.uint32)
+    for r in np.nonzero(keep_bits)[0]:
+        mask[r >> 5] |= np.uint32(1 << (r & 31))
+    for gf in (-1, 2):
+        for use_mask in (False, True):
+            for thr in (math.inf, 0.9, 0.7):
+                dist, ids, cnt = idx.search(q, k=20, group_filter=gf, row_mask=mask if use_mask else None,
+                                            max_distance=thr, algo="scan")
+                keep = np.ones(n, bool)
+                if gf >= 0:
+                    keep &= groups == gf
+                if use_mask:
+                    keep &= keep_bits
+                for i in range(2):
+                    full = parity.full_distances(rows, q[i], "f32")
+                    parity.check_topk(dist[i], ids[i], cnt[i], full, 20, threshold=None if math.isinf(thr) else thr,
+                                      keep=keep, label=f"gf={gf} mask={use_mask} thr={thr}")
+    # delete the current best rows: they must disappear, and come back when undeleted
+    dist, ids, cnt = idx.search(q[:1], k=5, algo="scan")
+    gone = ids[0][:3].copy()
+    idx.set_deleted(gone, True)
+    d2, i2, c2 = idx.search(q[:1], k=5, algo="scan")
+    keep = np.ones(n, bool)
+    keep[gone] = False
+    parity.check_topk(d2[0], i2[0], c2[0], parity.full_distances(rows, q[0], "f32"), 5, keep=keep, label="deleted")
+    idx.set_deleted(gone, False)
+    d3, i3, c3 = idx.search(q[:1], k=5, algo="scan")
+    assert i3[0].tolist() == ids[0].tolist()
+    # row range
+    d4, i4, c4 = idx.search(q[:1], k=5, row_begin=1000, row_end=2000, algo="scan")
+    keep = np.zeros(n, bool)
+    keep[1000:2000] = True
+    parity.check_topk(d4[0], i4[0], c4[0], parity.full_distances(rows, q[0], "f32"), 5, keep=keep, label="range")
+    idx.close()
+
+
+def test_edge_cases(hvs):
+    d = 16
+    idx = hvs.HvsIndex(d, "f32")
+    q = np.ones((1, d), np.float32)
+    # empty index
+    dist, ids, cnt = idx.search(q, k=10, algo="scan")
+    assert cnt[0] == 0 and np.all(np.isinf(dist)) and np.all(ids == -1)
+    rows = np.zeros((5, d), np.float32)
+    rows[0, 0] = 1.0  # distance 1 - 1/4 = 0.75
+    rows[1] = 1.0  # distance 0
+    rows[2] = -1.0  # distance 2
+    rows[3, 0] = 1.0
+    rows[3, 1] = -1.0  # orthogonal: distance exactly 1
+    idx.add(rows)
+    dist, ids, cnt = idx.search(q, k=10, algo="scan")
+    assert cnt[0] == 4 and ids[0][:4].tolist() == [1, 0, 3, 2]  # row 4 is all-zero: NaN, excluded
+    np.testing.assert_allclose(dist[0][:4], [0.0, 0.75, 1.0, 2.0], atol=1e-6)
+    # strict threshold: distance == 1.0 is excluded by "< 1.0"
+    dist, ids, cnt = idx.search(q, k=10, max_distance=1.0, algo="scan")
+    assert ids[0][: cnt[0]].tolist() == [1, 0]
+    # zero query: every distance NaN
+    dist, ids, cnt = idx.search(np.zeros((1, d), np.float32), k=3, algo="scan")
+    assert cnt[0] == 0
+    # LEAST ignores the NaN member
+    dist, ids, cnt = idx.search(np.stack([np.zeros(d, np.float32), np.ones(d, np.float32)]), k=1, fold=2, algo="scan")
+    assert cnt[0] == 1 and ids[0][0] == 1
+    # external ids
+    idx2 = hvs.HvsIndex(d, "f16")
+    idx2.add(rows, ids=np.array([100, 200, 300, 400, 500]))
+    dist, ids, cnt = idx2.search(q, k=2, algo="scan")
+    assert ids[0].tolist() == [200, 100]
+    # bad arguments surface as errors, not crashes
+    with pytest.raises(hvs.HvsError):
+        idx.search(q, k=0)
+    with pytest.raises(hvs.HvsError):
+        idx.search(q, k=5000)
+    with pytest.raises(ValueError):
+        idx.search(np.ones((1, d + 1), np.float32))
+    idx.close()
+    idx2.close()
+
+
+def test_golden_fixtures_on_gpu(hvs, golden_dir):
+    for name, dtype in (("cosine_d8_f32.npz", "f32"), ("cosine_d768_f32.npz", "f32"), ("cosine_d1536_f16.npz", "f16")):
+        g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+        rows, queries, sim = g["rows"], g["queries"], g["sim"]
+        idx = _mk(hvs, rows, dtype)
+        m = queries.shape[0]
+        dist, ids, cnt = idx.search(queries.astype(np.float32), k=10, fold=m, algo="scan")
+        full = np.min(1.0 - np.clip(sim, -1, 1), axis=1)
+        parity.check_topk(dist[0], ids[0], cnt[0], full, 10, label=name)
+        # the full distance column agrees too
+        col = idx.distances(queries.astype(np.float32))
+        np.testing.assert_allclose(col, full, atol=1e-5)
+        idx.close()
+
+
+def test_gather_and_update(hvs):
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((300, 40)).astype(np.float32)
+    for dtype in ("f32", "f16", "bf16"):
+        idx = _mk(hvs, rows, dtype)
+        pos = np.array([7, 0, 299, 7])
+        got = idx.gather(pos)
+        np.testing.assert_array_equal(got, po.round_storage(rows[pos], dtype).astype(np.float32))
+        new = rng.standard_normal((2, 40)).astype(np.float32)
+        idx.update(np.array([3, 4]), new)
+        np.testing.assert_array_equal(idx.gather([3, 4]), po.round_storage(new, dtype).astype(np.float32))
+        rows2 = rows.copy()
+        rows2[[3, 4]] = new
+        dist, ids, cnt = idx.search(new[:1], k=3, algo="scan")
+        parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows2, new[0], dtype), 3, label="update")
+        idx.close()
+
+
+def test_synthetic_fill_regenerates_on_host(hvs):
+    n, d = 5000, 1536
+    idx = hvs.HvsIndex(d, "f32")
+    idx.fill_synthetic(n, seed=1234, first_global_row=1_000_000, n_groups=64)
+    pos = np.array([0, 1, 77, 4999])
+    np.testing.assert_array_equal(idx.gather(pos), po.synth_rows(1234, 1_000_000, n, d)[pos])
+    rows = po.synth_rows(1234, 1_000_000, n, d)
+    q = po.synth_rows(4321, 0, 2, d)
+    dist, ids, cnt = idx.search(q, k=10, algo="scan")
+    for i in range(2):
+        full = parity.full_distances(rows, q[i], "f32")
+        parity.check_topk(dist[i], ids[i] - 1_000_000, cnt[i], full, 10, label="synthetic")
+    # group code = global row number mod 64
+    dist, ids, cnt = idx.search(q[:1], k=10, group_filter=3, algo="scan")
+    assert np.all(ids[0][: cnt[0]] % 64 == 3)
+    idx.close()
+
+
+def test_c_oracle_and_gpu_agree_at_medium_size(hvs):
+    rng = np.random.default_rng(8)
+    n, d = 200_000, 256
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((1, d)).astype(np.float32)
+    idx = _mk(hvs, rows, "f32")
+    dist, ids, cnt = idx.search(q, k=10, max_distance=0.8, algo="scan")
+    ci, cd = pgv_scan.scan_topk(rows, q, 10, threshold=0.8)
+    assert cnt[0] == len(ci)
+    np.testing.assert_allclose(dist[0][: cnt[0]], cd, atol=1e-5)
+    assert ids[0][: cnt[0]].tolist() == ci.tolist()
+    idx.close()
