@@ -1,8 +1,383 @@
-// placeholder until the MFMA path lands
-#include "hvs_internal.h"
-bool hvs_mfma_supported(hvs_index *, int, int, int) { return false; }
-int hvs_search_mfma(hvs_index *, const float *, const float *, int, int, int, int32_t, const uint32_t *, float, int64_t,
-                    int64_t, float *, int64_t *, int32_t *) {
-    hvs_set_error("MFMA path not built");
-    return 3;
+// Batched exact search and k-means assignment as an LDS-staged fp32 MFMA contraction (gfx950).
+//
+// S[a, n] = sum_k A[a, k] * X[n, k]      A = query embeddings (search) or centroids (k-means),
+//                                          X = the stored rows; both fp32, row pitch ld.
+// Block tile 128 (A rows) x 128 (corpus rows), 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 tiles of
+// v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain).  Corpus rows sit on the MFMA column
+// (= lane) axis, A rows on the accumulator-register axis, so per-corpus-row quantities (inverse norm,
+// filter bit, running argmin) are per-lane scalars and folding consecutive query embeddings (LEAST)
+// is a min over adjacent accumulator registers.
+//
+// The K loop streams 32-float slices of both operands through a double-buffered LDS image
+// (global -> VGPR -> ds_write_b128, XOR-swizzled so that the ds_read_b128 fragment reads are
+// conflict-free); loads for step g+1 are in flight while step g's 64 MFMAs per wave run.
+//
+// Search never writes the score matrix: the epilogue of every 128 x 128 tile compares each score
+// with the query's current admission bound tau (the k-th best distance seen so far by this block)
+// and appends the rare survivors to a small per-(block, query) candidate array; when an array nears
+// capacity one wave ranks it, keeps the best k and lowers tau.
+#include "hvs_gemm_tile.h"
+
+// ---------------------------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------------------------
+struct SearchParams {
+    const float *A;      // prepared queries [nA, ld]
+    const float *q_inv;  // [nA]
+    int nA;              // nq_out * fold
+    const float *X;      // corpus [*, ld]
+    const float *inv_norm;
+    const int32_t *groups;
+    const uint32_t *mask;
+    const uint32_t *deleted;
+    int32_t group_filter;
+    int64_t row_begin, row_end;
+    int ld, nks;
+    int fold;    // 1, 2 or 4 (embeddings folded by LEAST, consecutive A rows)
+    int nq_out;  // output queries
+    int k;
+    float thr;
+    int cap;          // capacity of one candidate array
+    uint64_t *cand;   // [gridDim.x, BM / fold, cap]
+    uint64_t *partial;  // [nq_out, S, k]
+    int QT, S;
+    int64_t T;      // corpus tiles in [row_begin, row_end)
+    int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
+};
+
+// One wave ranks the candidate array of one query, keeps the best `keep`, writes them in ascending
+// order to dst (dst == the array itself for an in-place compaction) and returns the new count.
+__device__ __forceinline__ int rank_select(const uint64_t *src, int cnt, int keep, uint64_t *dst, bool pad_dst,
+                                           volatile uint64_t *scratch, int lane, uint64_t *kth_key) {
+    uint64_t own[CAND_MAX / 64];
+    int rank[CAND_MAX / 64];
+#pragma unroll
+    for (int e = 0; e < CAND_MAX / 64; e++) {
+        const int i = lane + 64 * e;
+        own[e] = i < cnt ? src[i] : HVS_KEY_EMPTY;
+        rank[e] = 0;
+        if (i < cnt) scratch[i] = own[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < cnt; j++) {
+        const uint64_t kj = scratch[j];
+#pragma unroll
+        for (int e = 0; e < CAND_MAX / 64; e++) rank[e] += (kj < own[e]) ? 1 : 0;
+    }
+    const int newcnt = cnt < keep ? cnt : keep;
+    uint64_t kth = HVS_KEY_EMPTY;
+#pragma unroll
+    for (int e = 0; e < CAND_MAX / 64; e++) {
+        const int i = lane + 64 * e;
+        if (i < cnt && rank[e] < keep) {
+            dst[rank[e]] = own[e];
+            if (rank[e] == keep - 1) kth = own[e];
+        }
+    }
+    if (pad_dst)
+        for (int i = newcnt + lane; i < keep; i += 64) dst[i] = HVS_KEY_EMPTY;
+    // broadcast the k-th key (held by exactly one lane, if any)
+    const uint64_t has = __ballot(kth != HVS_KEY_EMPTY);
+    if (has) {
+        const int src_lane = __ffsll((unsigned long long)has) - 1;
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)kth, src_lane);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(kth >> 32), src_lane);
+        *kth_key = ((uint64_t)hi << 32) | lo;
+    } else {
+        *kth_key = HVS_KEY_EMPTY;
+    }
+    return newcnt;
+}
+
+template <int FOLD>
+__global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *stages = reinterpret_cast<float *>(smem);                          // 2 * STAGE_FLOATS
+    float *tau_lds = stages + 2 * STAGE_FLOATS;                               // [BM]
+    int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM]
+    float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM]
+    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(qinv_lds + BM);      // [4][CAND_MAX]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+
+    // block -> (query tile, corpus split); blocks that share a split sit on one XCD (b % 8) so that
+    // they stream the same corpus tiles through one L2
+    int qt, s;
+    if ((p.S & 7) == 0) {
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        qt = t % p.QT;
+        s = xcd + 8 * (t / p.QT);
+    } else {
+        qt = blockIdx.x % p.QT;
+        s = blockIdx.x / p.QT;
+    }
+    const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
+    const int64_t a_row0 = (int64_t)qt * BM;
+    constexpr int groups_per_tile = BM / FOLD;           // folded queries per tile
+    const int q_out0 = qt * groups_per_tile;             // first folded query of this tile
+    uint64_t *my_cand = p.cand + (size_t)blockIdx.x * groups_per_tile * p.cap;
+    volatile uint64_t *scratch = scratch_all + (size_t)wave * CAND_MAX;
+
+    for (int i = tid; i < BM; i += GT) {
+        tau_lds[i] = p.thr;
+        cnt_lds[i] = 0;
+        const int64_t ar = a_row0 + i;
+        qinv_lds[i] = ar < p.nA ? p.q_inv[ar] : 0.0f;
+    }
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    TileRegs regs;
+    const int64_t n_tiles = tile_hi - tile_lo;
+    const int64_t total_steps = n_tiles * p.nks;
+    const int64_t a_last = p.nA - 1, b_last = p.row_end - 1;
+
+    if (total_steps > 0) {
+        load_tiles(regs, p.A, a_row0, a_last, p.X, p.row_begin + tile_lo * BN, b_last, p.ld, 0, tid);
+        store_tiles(regs, stages, tid);
+    }
+    __syncthreads();
+
+    int64_t tile = tile_lo;
+    int ks = 0;
+    for (int64_t g = 0; g < total_steps; g++) {
+        const int cur = (int)(g & 1);
+        // next step's coordinates
+        int nks_next = ks + 1;
+        int64_t ntile = tile;
+        if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
+        const bool have_next = g + 1 < total_steps;
+        if (have_next)
+            load_tiles(regs, p.A, a_row0, a_last, p.X, p.row_begin + ntile * BN, b_last, p.ld, nks_next * BK, tid);
+
+        compute_step(acc, stages + cur * STAGE_FLOATS, wm, wn, lane);
+
+        if (ks == p.nks - 1) {
+            // ---- epilogue of tile `tile`: filter by tau, append survivors ----
+            const int64_t n_base = p.row_begin + tile * BN + wn * 64 + (lane & 31);
+            int64_t rows2[2];
+            bool ok2[2];
+            float invn2[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const int64_t row = n_base + nt * 32;
+                bool ok = row < p.row_end;
+                float invn = 0.0f;
+                if (ok) {
+                    invn = p.inv_norm[row];
+                    if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+                    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+                    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+                }
+                rows2[nt] = row;
+                ok2[nt] = ok;
+                invn2[nt] = invn;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int a_loc = wm * 64 + mt * 32 + 8 * gq + 4 * h;  // A row of register 4*gq (+0..3)
+                    const f32x4 qi = *reinterpret_cast<const f32x4 *>(qinv_lds + a_loc);
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        float d[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) d[e] = hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]);
+                        if (FOLD == 2) {
+                            d[0] = fminf(d[0], d[1]);
+                            d[2] = fminf(d[2], d[3]);
+                        } else if (FOLD == 4) {
+                            d[0] = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; e += FOLD) {
+                            const int ql = (a_loc + e) / FOLD;  // folded query, local to the tile
+                            if (ok2[nt] && d[e] < tau_lds[ql]) {
+                                int qv = ql;
+                                asm volatile("" : "+v"(qv));  // keep the address arithmetic inside this rare branch
+                                const int pos = atomicAdd(&cnt_lds[qv], 1);
+                                if (pos < p.cap) my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), (uint32_t)rows2[nt]);
+                                else *p.overflow = 1;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the 8 groups from being interleaved (VGPR pressure)
+                }
+            }
+            zero_acc(acc);
+        }
+
+        if (have_next) store_tiles(regs, stages + (cur ^ 1) * STAGE_FLOATS, tid);
+        __syncthreads();
+
+        if (ks == p.nks - 1) {
+            // ---- compaction: arrays that could overflow during the next tile ----
+            for (int base = 0; base < groups_per_tile; base += 64) {
+                const int ql = base + lane;
+                const bool need = ql < groups_per_tile && cnt_lds[ql] > p.cap - BN;
+                uint64_t pending = __ballot(need);
+                // waves share the work round-robin over the set bits
+                int nth = 0;
+                while (pending) {
+                    const int b = __ffsll((unsigned long long)pending) - 1;
+                    pending &= pending - 1;
+                    if ((nth++ & 3) != wave) continue;
+                    const int q = base + b;
+                    int c = cnt_lds[q];
+                    c = c > p.cap ? p.cap : c;
+                    uint64_t kth;
+                    uint64_t *arr = my_cand + (size_t)q * p.cap;
+                    const int nc = rank_select(arr, c, p.k, arr, false, scratch, lane, &kth);
+                    if (lane == 0) {
+                        cnt_lds[q] = nc;
+                        if (nc == p.k) tau_lds[q] = hvs_unord((uint32_t)(kth >> 32));
+                    }
+                }
+            }
+            // the next epilogue is a whole K loop (>= 1 barrier) away, so no extra barrier is needed
+            // unless the K loop has a single step
+            if (p.nks == 1) __syncthreads();
+        }
+        ks = nks_next;
+        tile = ntile;
+    }
+
+    // ---- publish: every folded query's best k, ascending, padded ----
+    __syncthreads();
+    for (int ql = wave; ql < groups_per_tile; ql += 4) {
+        const int qo = q_out0 + ql;
+        if (qo >= p.nq_out) break;
+        int c = cnt_lds[ql];
+        c = c > p.cap ? p.cap : c;
+        uint64_t kth;
+        rank_select(my_cand + (size_t)ql * p.cap, c, p.k, p.partial + ((size_t)qo * p.S + s) * p.k, true, scratch, lane, &kth);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side of the search
+// ---------------------------------------------------------------------------------------------
+int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
+                     int64_t *d_ids, int32_t *d_count);
+
+static size_t search_lds_bytes() { return (size_t)2 * STAGE_FLOATS * 4 + BM * 12 + (size_t)4 * CAND_MAX * 8; }
+
+static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
+
+bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k) {
+    (void)nq;
+    return idx->dtype == HVS_F32 && fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_MAX_K;
+}
+
+// copy query embeddings into groups of `pf` rows per output query (the last embedding repeated), with their norms
+__global__ void pad_fold_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, float *__restrict__ dst,
+                                float *__restrict__ dst_inv, int nq, int fold, int pf, int ld) {
+    const int row = blockIdx.x;  // destination row
+    const int q = row / pf, j = row % pf;
+    const int sj = j < fold ? j : fold - 1;
+    const float *s = src + ((size_t)q * fold + sj) * ld;
+    float *d = dst + (size_t)row * ld;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
+    if (threadIdx.x == 0) dst_inv[row] = src_inv[q * fold + sj];
+}
+
+int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
+                    int64_t *d_ids, int32_t *d_count) {
+    const int pf = padded_fold(fold);
+    const float *A = d_q;
+    const float *A_inv = d_qinv;
+    const int nA = nq * pf;
+    void *pad_ws = nullptr;
+    if (pf != fold) {
+        // slot 3 is free here: host staging in hvs_search uses it only for outputs/mask placed before this offset
+        const size_t bytes = (size_t)nA * idx->ld * 4 + (size_t)nA * 4 + 256;
+        HVS_HIP(hipMalloc(&pad_ws, bytes));
+        float *dst = (float *)pad_ws;
+        float *dst_inv = (float *)((char *)pad_ws + (((size_t)nA * idx->ld * 4 + 255) & ~(size_t)255));
+        pad_fold_kernel<<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, dst, dst_inv, nq, fold, pf, idx->ld);
+        HVS_HIP(hipGetLastError());
+        A = dst;
+        A_inv = dst_inv;
+    }
+
+    SearchParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = A;
+    p.q_inv = A_inv;
+    p.nA = nA;
+    p.X = (const float *)idx->rows;
+    p.inv_norm = idx->inv_norm;
+    p.groups = idx->groups;
+    p.mask = d_mask;
+    p.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
+    p.group_filter = group_filter;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    p.ld = idx->ld;
+    p.nks = (idx->ld + BK - 1) / BK;
+    p.fold = pf;
+    p.nq_out = nq;
+    p.k = k;
+    p.thr = thr;
+    int cap = k + 2 * BN;
+    cap = (cap + 63) / 64 * 64;
+    if (cap > CAND_MAX) cap = CAND_MAX;
+    p.cap = cap;
+    p.QT = (nA + BM - 1) / BM;
+    p.T = (row_end - row_begin + BN - 1) / BN;
+    // splits: fill 2 blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
+    int S = (512 + p.QT - 1) / p.QT;
+    S = (S + 7) / 8 * 8;
+    if ((int64_t)S > p.T) S = (int)p.T;
+    if (S >= 8) S = S / 8 * 8;
+    if (S < 1) S = 1;
+    p.S = S;
+    const int grid = p.QT * S;
+    const int groups_per_tile = BM / pf;
+
+    void *cand = nullptr, *bufA = nullptr, *bufB = nullptr;
+    const size_t cand_bytes = (size_t)grid * groups_per_tile * cap * 8;
+    const size_t part_bytes = (size_t)nq * S * k * 8;
+    const int P2 = (S + 31) / 32;
+    HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
+    HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 256, &bufB));
+    bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
+    int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
+    HVS_HIP(hipMemsetAsync(overflow, 0, 4, idx->stream));
+    p.cand = (uint64_t *)cand;
+    p.partial = (uint64_t *)bufA;
+    p.overflow = overflow;
+
+    const size_t lds = search_lds_bytes();
+    HVS_TRY(hvs_prof_begin(idx));
+#define HVS_LAUNCH_SEARCH(F)                                                                                         \
+    do {                                                                                                             \
+        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        mfma_search_kernel<F><<<grid, GT, lds, idx->stream>>>(p);                                                    \
+    } while (0)
+    if (pf == 1) HVS_LAUNCH_SEARCH(1);
+    else if (pf == 2) HVS_LAUNCH_SEARCH(2);
+    else HVS_LAUNCH_SEARCH(4);
+#undef HVS_LAUNCH_SEARCH
+    HVS_HIP(hipGetLastError());
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
+    HVS_TRY(hvs_prof_begin(idx));
+    HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count));
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+    int h_overflow = 0;
+    if (pad_ws || true) {
+        HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    if (pad_ws) HVS_HIP(hipFree(pad_ws));
+    HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
+    return 0;
 }

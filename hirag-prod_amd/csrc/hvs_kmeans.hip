@@ -1,6 +1,269 @@
-// placeholder until the k-means kernels land
-#include "hvs_internal.h"
-extern "C" int hvs_kmeans_assign(hvs_index *, const float *, int, int32_t *, float *, int64_t *, int) {
-    hvs_set_error("hvs_kmeans_assign: not built");
-    return 3;
+// k-means E-step (argmin over centroids) on the fp32 MFMA tile machinery, plus the M-step partial sums.
+//
+// assign[r] = argmin_j |x_r - c_j|^2 = argmin_j (|c_j|^2 - 2 x_r . c_j), lowest j on ties.
+// Blocks own a 128-centroid tile and stream the corpus (the blocks of the 8 XCD groups that share a
+// corpus split read the same tiles through one L2, so HBM sees every row once per iteration); each
+// block writes, per corpus row, the best (value, centroid) of its tile as one 64-bit key, and a
+// second kernel takes the minimum key over the centroid tiles.  No atomics, bit-reproducible.
+#include "hvs_gemm_tile.h"
+
+struct AssignParams {
+    const float *C;        // centroids [K, ld] (padded copy)
+    const float *c_norm;   // [K] |c|^2
+    int K;
+    const float *X;        // corpus
+    int64_t n;             // rows
+    int ld, nks;
+    int CT, S;             // centroid tiles, corpus splits
+    int64_t T;             // corpus tiles
+    uint64_t *best;        // [CT, n] keys
+};
+
+__global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *stages = reinterpret_cast<float *>(smem);
+    float *cn_lds = stages + 2 * STAGE_FLOATS;                                   // [BM]
+    uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + BM);                   // [2][64] keys (wm = 1 -> wm = 0)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5;
+
+    int ct, s;
+    if ((p.S & 7) == 0) {
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        ct = t % p.CT;
+        s = xcd + 8 * (t / p.CT);
+    } else {
+        ct = blockIdx.x % p.CT;
+        s = blockIdx.x / p.CT;
+    }
+    const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
+    const int64_t a_row0 = (int64_t)ct * BM;
+    for (int i = tid; i < BM; i += GT) {
+        const int64_t c = a_row0 + i;
+        cn_lds[i] = c < p.K ? p.c_norm[c] : __builtin_inff();  // padding centroids never win
+    }
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    TileRegs regs;
+    const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
+    const int64_t a_last = p.K - 1, b_last = p.n - 1;
+    if (total_steps > 0) {
+        load_tiles(regs, p.C, a_row0, a_last, p.X, tile_lo * BN, b_last, p.ld, 0, tid);
+        store_tiles(regs, stages, tid);
+    }
+    __syncthreads();
+
+    int64_t tile = tile_lo;
+    int ks = 0;
+    for (int64_t g = 0; g < total_steps; g++) {
+        const int cur = (int)(g & 1);
+        int ks_next = ks + 1;
+        int64_t ntile = tile;
+        if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
+        const bool have_next = g + 1 < total_steps;
+        if (have_next) load_tiles(regs, p.C, a_row0, a_last, p.X, ntile * BN, b_last, p.ld, ks_next * BK, tid);
+
+        compute_step(acc, stages + cur * STAGE_FLOATS, wm, wn, lane);
+
+        uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
+        const bool last = ks == p.nks - 1;
+        if (last) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                uint64_t b = HVS_KEY_EMPTY;
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int a_loc = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = fmaf(-2.0f, acc[mt][nt][e], cn_lds[a_loc]);
+                        if (v == v) {
+                            const uint64_t key = hvs_make_key(hvs_ord(v), (uint32_t)(a_row0 + a_loc));
+                            b = key < b ? key : b;
+                        }
+                    }
+                // the other lane half holds the other centroid rows of the same corpus row
+                const uint32_t olo = __shfl_xor((uint32_t)b, 32);
+                const uint32_t ohi = __shfl_xor((uint32_t)(b >> 32), 32);
+                const uint64_t o = ((uint64_t)ohi << 32) | olo;
+                bestk[nt] = o < b ? o : b;
+            }
+            zero_acc(acc);
+            if (wm == 1 && h == 0) {
+                xch[(wn * 2 + 0) * 32 + (lane & 31)] = bestk[0];
+                xch[(wn * 2 + 1) * 32 + (lane & 31)] = bestk[1];
+            }
+        }
+
+        if (have_next) store_tiles(regs, stages + (cur ^ 1) * STAGE_FLOATS, tid);
+        __syncthreads();
+
+        if (last && wm == 0 && h == 0) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const uint64_t o = xch[(wn * 2 + nt) * 32 + (lane & 31)];
+                const uint64_t b = o < bestk[nt] ? o : bestk[nt];
+                const int64_t row = tile * BN + wn * 64 + nt * 32 + (lane & 31);
+                if (row < p.n) p.best[(size_t)ct * p.n + row] = b;
+            }
+        }
+        if (last && p.nks == 1) __syncthreads();  // xch is rewritten a whole K loop later otherwise
+        ks = ks_next;
+        tile = ntile;
+    }
+}
+
+// assign[r] = centroid of the minimum key over the CT tiles; deleted rows -> -1
+__global__ void kmeans_reduce_kernel(const uint64_t *__restrict__ best, int CT, int64_t n, const uint32_t *__restrict__ deleted,
+                                     int32_t *__restrict__ assign) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t b = HVS_KEY_EMPTY;
+        for (int t = 0; t < CT; t++) {
+            const uint64_t k = best[(size_t)t * n + r];
+            b = k < b ? k : b;
+        }
+        int32_t a = b == HVS_KEY_EMPTY ? -1 : (int32_t)(uint32_t)b;
+        if (deleted && ((deleted[r >> 5] >> (r & 31)) & 1u)) a = -1;
+        assign[r] = a;
+    }
+}
+
+// c_pad[j][0..ld) = centroid j zero-padded; c_norm[j] = |c_j|^2.  One wave per centroid.
+__global__ void prep_centroids_kernel(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ c_norm,
+                                      int K, int dim, int ld) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j >= K) return;
+    float s = 0.0f;
+    for (int c = lane; c < ld; c += 64) {
+        const float v = c < dim ? src[(size_t)j * dim + c] : 0.0f;
+        dst[(size_t)j * ld + c] = v;
+        s = fmaf(v, v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) c_norm[j] = s;
+}
+
+// M-step partial sums: one wave per row, 256-byte contiguous float atomics into sums[assign[r]];
+// counts through a per-block LDS histogram when K fits, else direct atomics.
+__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__restrict__ X, const int32_t *__restrict__ assign,
+                                                                int64_t n, int dim, int ld, int K, float *sums,
+                                                                unsigned long long *counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        const int a = assign[r];
+        if (a < 0) continue;
+        const float *x = X + (size_t)r * ld;
+        float *dst = sums + (size_t)a * dim;
+        for (int c = lane; c < dim; c += 64) atomicAdd(dst + c, x[c]);
+        if (lane == 0) atomicAdd(counts + a, 1ull);
+    }
+}
+
+static size_t assign_lds_bytes() { return (size_t)2 * STAGE_FLOATS * 4 + BM * 4 + 2 * 64 * 8; }
+
+extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids, int32_t *out_assign,
+                                 float *out_sums, int64_t *out_counts, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_kmeans_assign: idx is NULL");
+    HVS_REQUIRE(idx->dtype == HVS_F32, "hvs_kmeans_assign: the index must store f32 rows");
+    HVS_REQUIRE(centroids && out_assign, "hvs_kmeans_assign: NULL argument");
+    HVS_REQUIRE(n_centroids >= 1, "hvs_kmeans_assign: need at least one centroid");
+    HVS_REQUIRE((out_sums == nullptr) == (out_counts == nullptr), "hvs_kmeans_assign: pass both out_sums and out_counts or neither");
+    const int64_t n = idx->n;
+    if (n == 0) {
+        return 0;
+    }
+    HVS_HIP(hipSetDevice(idx->device));
+    const int K = n_centroids, dim = idx->dim, ld = idx->ld;
+    hipStream_t st = idx->stream;
+
+    // workspace 0: padded centroids + norms (+ raw host copy); workspace 1: best keys; workspace 3: host staging
+    const size_t cpad_bytes = (size_t)K * ld * 4;
+    const size_t norm_off = (cpad_bytes + 255) & ~(size_t)255;
+    const size_t raw_off = (norm_off + (size_t)K * 4 + 255) & ~(size_t)255;
+    const size_t raw_bytes = on_device ? 0 : (size_t)K * dim * 4;
+    void *ws0 = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 0, raw_off + raw_bytes, &ws0));
+    const float *src = centroids;
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync((char *)ws0 + raw_off, centroids, raw_bytes, hipMemcpyHostToDevice, st));
+        src = (const float *)((char *)ws0 + raw_off);
+    }
+    float *c_pad = (float *)ws0;
+    float *c_norm = (float *)((char *)ws0 + norm_off);
+    prep_centroids_kernel<<<(K + 3) / 4, 256, 0, st>>>(src, c_pad, c_norm, K, dim, ld);
+    HVS_HIP(hipGetLastError());
+
+    AssignParams p;
+    memset(&p, 0, sizeof(p));
+    p.C = c_pad;
+    p.c_norm = c_norm;
+    p.K = K;
+    p.X = (const float *)idx->rows;
+    p.n = n;
+    p.ld = ld;
+    p.nks = (ld + BK - 1) / BK;
+    p.CT = (K + BM - 1) / BM;
+    p.T = (n + BN - 1) / BN;
+    int S = (512 + p.CT - 1) / p.CT;
+    S = (S + 7) / 8 * 8;
+    if ((int64_t)S > p.T) S = (int)p.T;
+    if (S >= 8) S = S / 8 * 8;
+    if (S < 1) S = 1;
+    p.S = S;
+    void *best = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 1, (size_t)p.CT * n * 8, &best));
+    p.best = (uint64_t *)best;
+
+    int32_t *d_assign = out_assign;
+    float *d_sums = out_sums;
+    int64_t *d_counts = out_counts;
+    if (!on_device) {
+        const size_t o_sums = ((size_t)n * 4 + 255) & ~(size_t)255;
+        const size_t o_cnt = (o_sums + (out_sums ? (size_t)K * dim * 4 : 0) + 255) & ~(size_t)255;
+        void *stage = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 3, o_cnt + (size_t)K * 8, &stage));
+        d_assign = (int32_t *)stage;
+        if (out_sums) {
+            d_sums = (float *)((char *)stage + o_sums);
+            d_counts = (int64_t *)((char *)stage + o_cnt);
+        }
+    }
+
+    const size_t lds = assign_lds_bytes();
+    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HVS_TRY(hvs_prof_begin(idx));
+    kmeans_assign_kernel<<<p.CT * S, GT, lds, st>>>(p);
+    HVS_HIP(hipGetLastError());
+    int rg = (int)((n + 255) / 256);
+    if (rg > 256 * 8) rg = 256 * 8;
+    kmeans_reduce_kernel<<<rg, 256, 0, st>>>(p.best, p.CT, n, idx->n_deleted > 0 ? idx->deleted : nullptr, d_assign);
+    HVS_HIP(hipGetLastError());
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_KMEANS_ASSIGN));
+
+    if (out_sums) {
+        HVS_HIP(hipMemsetAsync(d_sums, 0, (size_t)K * dim * 4, st));
+        HVS_HIP(hipMemsetAsync(d_counts, 0, (size_t)K * 8, st));
+        HVS_TRY(hvs_prof_begin(idx));
+        kmeans_accumulate_kernel<<<256 * 8, 256, 0, st>>>((const float *)idx->rows, d_assign, n, dim, ld, K, d_sums,
+                                                          (unsigned long long *)d_counts);
+        HVS_HIP(hipGetLastError());
+        HVS_TRY(hvs_prof_end(idx, HVS_PROF_KMEANS_UPDATE));
+    }
+    if (!on_device) {
+        HVS_HIP(hipMemcpyAsync(out_assign, d_assign, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        if (out_sums) {
+            HVS_HIP(hipMemcpyAsync(out_sums, d_sums, (size_t)K * dim * 4, hipMemcpyDeviceToHost, st));
+            HVS_HIP(hipMemcpyAsync(out_counts, d_counts, (size_t)K * 8, hipMemcpyDeviceToHost, st));
+        }
+        HVS_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
 }

@@ -1,0 +1,141 @@
+"""GPU tier: the batched MFMA search path and the k-means E/M step against the oracle."""
+
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kmeans_oracle, pgvector_oracle as po
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hvs():
+    import hirag_prod_amd
+
+    assert hirag_prod_amd.device_count() >= 1
+    return hirag_prod_amd
+
+
+def _check_all(rows, q, fold, k, dist, ids, cnt, thr=None, keep=None, label=""):
+    nq = q.shape[0] // fold
+    rows64 = rows.astype(np.float64)
+    for i in range(nq):
+        full = parity.full_distances(rows64, q[i * fold : (i + 1) * fold], "f32")
+        parity.check_topk(dist[i], ids[i], cnt[i], full, k, threshold=thr, keep=keep, label=f"{label} q={i}")
+
+
+@pytest.mark.parametrize("n,d", [(1000, 96), (20000, 256), (5000, 1536), (130, 40)])
+def test_mfma_search_matches_oracle(hvs, n, d):
+    rng = np.random.default_rng(n * 7 + d)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[3] = 0.0
+    rows[8] = rows[2]
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    for nq, k in ((1, 10), (37, 1), (160, 10), (64, 100), (300, 128)):
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+        q[0] = rows[2]  # an exact hit with an exact tie (rows 2 and 8)
+        dist, ids, cnt = idx.search(q, k=k, algo="mfma")
+        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"mfma n={n} d={d} nq={nq} k={k}")
+        # the two independent kernels agree with each other as well
+        d2, i2, c2 = idx.search(q[:8], k=k, algo="scan")
+        np.testing.assert_array_equal(c2, cnt[:8])
+        np.testing.assert_allclose(d2, dist[:8], atol=2e-6)
+    idx.close()
+
+
+@pytest.mark.parametrize("fold", [2, 3, 4])
+def test_mfma_fold_threshold_filters(hvs, fold):
+    rng = np.random.default_rng(fold)
+    n, d = 9000, 128
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    groups = (np.arange(n) % 3).astype(np.int32)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows, group_codes=groups)
+    nq = 40
+    q = rng.standard_normal((nq * fold, d)).astype(np.float32)
+    keep_bits = rng.random(n) < 0.5
+    mask = np.zeros((n + 31) // 32, dtype=np.uint32)
+    for r in np.nonzero(keep_bits)[0]:
+        mask[r >> 5] |= np.uint32(1 << (r & 31))
+    for gf, use_mask, thr in ((-1, False, math.inf), (1, False, 0.9), (-1, True, 0.85), (2, True, math.inf)):
+        dist, ids, cnt = idx.search(q, k=10, fold=fold, group_filter=gf, row_mask=mask if use_mask else None,
+                                    max_distance=thr, algo="mfma")
+        keep = np.ones(n, bool)
+        if gf >= 0:
+            keep &= groups == gf
+        if use_mask:
+            keep &= keep_bits
+        _check_all(rows, q, fold, 10, dist, ids, cnt, thr=None if math.isinf(thr) else thr, keep=keep,
+                   label=f"fold={fold} gf={gf} mask={use_mask} thr={thr}")
+    # deleted rows and row ranges
+    idx.set_deleted(np.arange(0, n, 2), True)
+    dist, ids, cnt = idx.search(q, k=5, fold=fold, row_begin=1001, row_end=7777, algo="mfma")
+    keep = np.zeros(n, bool)
+    keep[1001:7777] = True
+    keep[::2] = False
+    _check_all(rows, q, fold, 5, dist, ids, cnt, keep=keep, label=f"fold={fold} deleted+range")
+    idx.close()
+
+
+def test_mfma_auto_dispatch_and_synthetic(hvs):
+    n, d = 40_000, 1536
+    idx = hvs.HvsIndex(d, "f32")
+    idx.fill_synthetic(n, seed=1234)
+    rows = po.synth_rows(1234, 0, n, d)
+    q = po.synth_rows(4321, 0, 64, d)
+    # planted neighbours: rows 100..109 = q[5] + 0.05 * noise
+    noise = po.synth_rows(99, 0, 10, d)
+    planted = q[5][None, :] + 0.05 * noise
+    idx.update(np.arange(100, 110), planted)
+    rows[100:110] = planted
+    dist, ids, cnt = idx.search(q, k=10)  # auto -> MFMA for 64 queries
+    _check_all(rows, q, 1, 10, dist, ids, cnt, label="synthetic")
+    assert sorted(ids[5].tolist()) == list(range(100, 110))
+    idx.close()
+
+
+@pytest.mark.parametrize("n,d,kc", [(5000, 64, 5), (3000, 100, 200), (4100, 1536, 300)])
+def test_kmeans_assign_matches_oracle(hvs, n, d, kc):
+    rng = np.random.default_rng(n + kc)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    c = x[rng.choice(n, kc, replace=False)].copy()
+    c[1] = c[0]  # duplicate centroid: ties go to the lower index
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(x)
+    assign, sums, counts = idx.kmeans_assign(c)
+    exp, margin = kmeans_oracle.assign(x, c)
+    scale = float(np.mean(np.sum(x.astype(np.float64) ** 2, axis=1)))
+    # centroids 0 and 1 are identical: an exact tie, which must go to index 0 on the GPU as in numpy
+    tie01 = exp == 0
+    assert tie01.any() and not np.any(exp == 1)
+    np.testing.assert_array_equal(assign[tie01], 0)
+    assert not np.any(assign == 1)
+    safe = (margin > 1e-5 * scale) | tie01  # below this an fp32 dot product may legitimately flip the argmin
+    assert safe.mean() > 0.99
+    np.testing.assert_array_equal(assign[safe], exp[safe])
+    # rows that are themselves centroids are assigned to them (distance 0)
+    _, esums, ecounts = kmeans_oracle.update(x, assign, c)
+    np.testing.assert_array_equal(counts, ecounts)
+    np.testing.assert_allclose(sums, esums, rtol=1e-4, atol=1e-3)
+    # assignment only
+    a2, s2, c2 = idx.kmeans_assign(c, want_sums=False)
+    np.testing.assert_array_equal(a2, assign)
+    assert s2 is None and c2 is None
+    idx.close()
+
+
+def test_kmeans_golden(hvs, golden_dir):
+    for name in ("kmeans_n512_d16_k8.npz", "kmeans_n300_d64_k5.npz"):
+        g = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+        idx = hvs.HvsIndex(g["x"].shape[1], "f32")
+        idx.add(g["x"])
+        assign, sums, counts = idx.kmeans_assign(g["c0"])
+        np.testing.assert_array_equal(assign, g["assign0"])  # sklearn's own E-step
+        new_c = sums / np.maximum(counts, 1)[:, None]
+        np.testing.assert_allclose(new_c, g["centers1"], atol=1e-4)
+        idx.close()
