@@ -59,15 +59,17 @@ class ShardedSearch:
         if self.world == 1:
             return d, i, c
         nq = d.shape[0]
-        gd = torch.empty((self.world, nq, k), dtype=d.dtype, device=d.device)
-        gi = torch.empty((self.world, nq, k), dtype=i.dtype, device=i.device)
-        gc = torch.empty((self.world, nq), dtype=c.dtype, device=c.device)
+        # outputs are the ranks' tensors concatenated along dim 0 (the layout every backend accepts)
+        gd = torch.empty((self.world * nq, k), dtype=d.dtype, device=d.device)
+        gi = torch.empty((self.world * nq, k), dtype=i.dtype, device=i.device)
+        gc = torch.empty((self.world * nq,), dtype=c.dtype, device=c.device)
         # three small collectives; each moves world * nq * k * {4, 8} (or nq * 4) bytes
         dist.all_gather_into_tensor(gd, d.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gi, i.contiguous(), group=self.group)
         dist.all_gather_into_tensor(gc, c.contiguous(), group=self.group)
-        return self.merge(gd.permute(1, 0, 2).contiguous(), gi.permute(1, 0, 2).contiguous(),
-                          gc.permute(1, 0).contiguous(), k)
+        w = self.world
+        return self.merge(gd.view(w, nq, k).permute(1, 0, 2).contiguous(), gi.view(w, nq, k).permute(1, 0, 2).contiguous(),
+                          gc.view(w, nq).permute(1, 0).contiguous(), k)
 
 
 def sharded_kmeans_step(assign_fn: Callable, centroids: torch.Tensor, group: Optional[dist.ProcessGroup] = None):

@@ -1,0 +1,568 @@
+"""``HipVectorStore``: drop-in for the reference's pgvector store on the dense-retrieval path.
+
+It implements ``BaseVDB`` (``src/hirag_prod/storage/base_vdb.py:5-62``) with the argument meaning,
+defaults, return shapes and errors of ``PGVector`` (``src/hirag_prod/storage/pgvector.py``), and is
+injected with ``HiRAG.create(vdb=HipVectorStore.create(embedding_func))``.  Vectors live in HBM
+(one ``HvsIndex`` per embedded table); the distance arithmetic, the LEAST fold, the threshold and
+the ORDER BY ... LIMIT all run in the HIP kernels.  Row metadata (the non-vector columns) stays on
+the host in plain Python structures: it is what PostgreSQL would return next to the distance and
+takes no part in the arithmetic.
+
+What is NOT here: the graph tables and PageRank (``upsert_graph``, ``query_node``,
+``pagerank_top_chunks_with_reset``) and SQLAlchemy-expression arguments of ``query_by_keys``; a store
+created with ``delegate=<PGVector instance>`` forwards those calls, otherwise they raise
+``NotImplementedError``.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import logging
+import math
+import time
+from datetime import datetime
+from typing import Any, Callable, Dict, List, Literal, Optional, Union
+
+import numpy as np
+
+from .vdb_interface import (
+    DEFAULT_DISTANCE_THRESHOLD,
+    DEFAULT_QUERY_TOP_K,
+    DEFAULT_QUERY_TOP_N,
+    TABLES,
+    BaseVDB,
+)
+
+logger = logging.getLogger(__name__)
+
+_HALF_MAX = 65504.0
+_MAX_FOLD = 8  # HVS_MAX_FOLD
+
+
+class StoredVector(list):
+    """A stored embedding as the reference's callers expect it: a list that also answers
+    ``to_list()`` (``pgvector.HalfVector``) and ``tolist()`` (``numpy``), see
+    ``src/hirag_prod/storage/query_service.py:216-220``."""
+
+    def to_list(self):
+        return list(self)
+
+    def tolist(self):
+        return list(self)
+
+
+class _Table:
+    """Host-side state of one table: metadata rows, primary-key map, filter columns."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.columns, self.pk, self.has_vector = TABLES[name]
+        self.colset = set(self.columns)
+        self.rows: List[Optional[dict]] = []  # position -> row (None = deleted)
+        self.pk_map: Dict[tuple, int] = {}
+        self.index = None  # HvsIndex for embedded tables
+        # filter columns as arrays, grown geometrically
+        self.group = np.zeros(0, dtype=np.int32)
+        self.ws_code = np.zeros(0, dtype=np.int32)
+        self.kb_code = np.zeros(0, dtype=np.int32)
+        self.uri_code = np.zeros(0, dtype=np.int32)
+        self.private = np.zeros(0, dtype=bool)
+        self.live = np.zeros(0, dtype=bool)
+
+    def _grow(self, n: int) -> None:
+        if n <= len(self.group):
+            return
+        cap = max(n, 2 * len(self.group), 1024)
+        for name in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
+            old = getattr(self, name)
+            new = np.zeros(cap, dtype=old.dtype)
+            new[: len(old)] = old
+            setattr(self, name, new)
+
+
+class HipVectorStore(BaseVDB):
+    """GPU-resident vector store with the reference's ``PGVector`` behaviour on the retrieval path."""
+
+    def __init__(
+        self,
+        embedding_func: Optional[Callable],
+        vector_type: Literal["vector", "halfvec", "bf16"] = "halfvec",
+        embedding_dimension: Optional[int] = None,
+        device: int = 0,
+        delegate: Any = None,
+        tokenizer: Optional[Callable[[str], tuple]] = None,
+        translator: Optional[Callable[[str], Any]] = None,
+        index_factory: Optional[Callable[[int, str, int], Any]] = None,
+    ):
+        if vector_type not in ("vector", "halfvec", "bf16"):
+            raise ValueError(f"vector_type must be 'vector', 'halfvec' or 'bf16', got {vector_type!r}")
+        self.embedding_func = embedding_func
+        self.vector_type = vector_type
+        self.dtype = {"vector": "f32", "halfvec": "f16", "bf16": "bf16"}[vector_type]
+        self.embedding_dimension = embedding_dimension
+        self.device = device
+        self.delegate = delegate
+        self.tokenizer = tokenizer
+        self.translator = translator
+        self._index_factory = index_factory
+        self.tables: Dict[str, _Table] = {name: _Table(name) for name in TABLES}
+        self._ws_codes: Dict[str, int] = {}
+        self._kb_codes: Dict[str, int] = {}
+        self._uri_codes: Dict[str, int] = {}
+        self._group_codes: Dict[tuple, int] = {}
+        self._lock = asyncio.Lock()
+
+    # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
+    @classmethod
+    def create(cls, embedding_func: Optional[Callable], vector_type: str = "halfvec", **kwargs) -> "HipVectorStore":
+        return cls(embedding_func, vector_type=vector_type, **kwargs)
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def get_model(self, table_name: str) -> _Table:
+        table = self.tables.get(table_name)
+        if not table:
+            if self.delegate is not None and table_name in getattr(self.delegate, "tables", {}):
+                raise NotImplementedError(f"table {table_name} is served by the delegate store")
+            raise ValueError(f"No table found for table {table_name}")  # pgvector.py:63-67
+        return table
+
+    def _make_index(self, dim: int):
+        if self._index_factory is not None:
+            return self._index_factory(dim, self.dtype, self.device)
+        from .index import HvsIndex  # fails loudly when libhvs.so or the GPU is missing
+
+        return HvsIndex(dim, self.dtype, device=self.device)
+
+    def _ensure_index(self, table: _Table, dim: int):
+        if table.index is None:
+            if self.embedding_dimension is None:
+                self.embedding_dimension = dim
+            table.index = self._make_index(self.embedding_dimension)
+        return table.index
+
+    @staticmethod
+    def _code(mapping: Dict[Any, int], key: Any) -> int:
+        code = mapping.get(key)
+        if code is None:
+            code = len(mapping)
+            mapping[key] = code
+        return code
+
+    @staticmethod
+    def _to_list(embedding):
+        return embedding.tolist() if hasattr(embedding, "tolist") else list(embedding)
+
+    async def _init_vdb(self, embedding_dimension: Optional[int] = None, *args, **kwargs):
+        """Create the embedded tables' indexes (``PGVector._init_vdb``, pgvector.py:704-726)."""
+        if embedding_dimension is not None:
+            self.embedding_dimension = int(embedding_dimension)
+        if self.embedding_dimension is None:
+            return
+        for table in self.tables.values():
+            if table.has_vector:
+                await asyncio.to_thread(self._ensure_index, table, self.embedding_dimension)
+
+    # -- ingest ------------------------------------------------------------------------------------
+    async def upsert_texts(
+        self,
+        texts_to_upsert: List[str],
+        properties_list: List[dict],
+        table_name: str,
+        with_tokenization: bool = False,
+        with_translation: bool = False,
+        mode: Literal["append", "overwrite"] = "append",
+    ):
+        """Embed and insert; rows whose primary key already exists are left untouched
+        (``INSERT ... ON CONFLICT DO NOTHING``, pgvector.py:80-187)."""
+        if len(texts_to_upsert) != len(properties_list):
+            raise ValueError("texts_to_upsert and properties_list must have the same length")
+        table = self.get_model(table_name)
+        if not table.has_vector:
+            raise ValueError(f"table {table_name} has no vector column")
+        start = time.perf_counter()
+        embs = await self.embedding_func(texts_to_upsert)
+        now = datetime.now()
+        rows: List[dict] = []
+        for i in range(len(properties_list)):
+            row = dict(properties_list[i] or {})
+            if with_tokenization and self.tokenizer is not None:
+                (row["token_list"], row["token_start_index_list"], row["token_end_index_list"]) = self.tokenizer(
+                    texts_to_upsert[i]
+                )
+            if with_translation and self.translator is not None:
+                translated = self.translator(texts_to_upsert[i])
+                if asyncio.iscoroutine(translated):
+                    translated = await translated
+                row["translation"] = getattr(translated, "text", translated)
+                if with_tokenization and self.tokenizer is not None:
+                    (
+                        row["translation_token_list"],
+                        row["translation_token_start_index_list"],
+                        row["translation_token_end_index_list"],
+                    ) = self.tokenizer(row["translation"])
+            row["vector"] = self._to_list(embs[i])
+            row["updatedAt"] = now
+            rows.append({k: v for k, v in row.items() if k in table.colset})
+        if not rows:
+            logger.info(f"[upsert_texts] No rows to upsert into '{table_name}', mode={mode}, elapsed={time.perf_counter() - start:.3f}s")
+            return rows
+
+        async with self._lock:
+            new_vecs, new_rows = [], []
+            seen_in_batch = set()
+            for row in rows:
+                pk = tuple(row.get(c) for c in table.pk)
+                if any(v is None for v in pk):
+                    raise ValueError(f"null value in primary key {table.pk} of table {table_name}")
+                if pk in table.pk_map or pk in seen_in_batch:
+                    continue  # first write wins
+                vec = np.asarray(row["vector"], dtype=np.float64)
+                dim = self.embedding_dimension or vec.shape[0]
+                if vec.ndim != 1 or vec.shape[0] != dim:
+                    raise ValueError(f"expected {dim} dimensions, not {vec.shape[0] if vec.ndim == 1 else vec.shape}")
+                if not np.all(np.isfinite(vec)):
+                    raise ValueError("NaN or infinite value not allowed in vector")
+                if self.dtype == "f16" and np.any(np.abs(vec) > _HALF_MAX):
+                    raise ValueError("value out of range for type halfvec")
+                seen_in_batch.add(pk)
+                new_vecs.append(vec.astype(np.float32))
+                new_rows.append((pk, row))
+            if new_rows:
+                dim = len(new_vecs[0])
+                index = self._ensure_index(table, dim)
+                first = len(table.rows)
+                n_new = len(new_rows)
+                table._grow(first + n_new)
+                groups = np.empty(n_new, dtype=np.int32)
+                for j, (pk, row) in enumerate(new_rows):
+                    pos = first + j
+                    ws, kb = row.get("workspaceId"), row.get("knowledgeBaseId")
+                    groups[j] = self._code(self._group_codes, (ws, kb))
+                    table.group[pos] = groups[j]
+                    table.ws_code[pos] = self._code(self._ws_codes, ws)
+                    table.kb_code[pos] = self._code(self._kb_codes, kb)
+                    table.uri_code[pos] = self._code(self._uri_codes, row.get("uri"))
+                    table.private[pos] = bool(row.get("private", False))
+                    table.live[pos] = True
+                    stored = dict(row)
+                    stored.pop("vector", None)  # the vector lives in HBM
+                    table.rows.append(stored)
+                    table.pk_map[pk] = pos
+                mat = np.stack(new_vecs)
+                lo, hi = await asyncio.to_thread(index.add, mat, None, groups)
+                assert lo == first and hi == first + n_new, "host rows and device rows out of step"
+        logger.info("[upsert_texts] Upserted %d into '%s', mode=%s, elapsed=%.3fs", len(rows), table_name, mode,
+                    time.perf_counter() - start)
+        return rows
+
+    async def upsert_file(self, file, table_name: str = "Files", mode: str = "append"):
+        """Insert one Files row unless its primary key exists (pgvector.py:475-503)."""
+        table = self.get_model(table_name)
+        row = dict(file)
+        row["updatedAt"] = datetime.now()
+        row = {k: v for k, v in row.items() if k in table.colset}
+        pk = tuple(row.get(c) for c in table.pk)
+        async with self._lock:
+            if pk not in table.pk_map:
+                pos = len(table.rows)
+                table._grow(pos + 1)
+                table.ws_code[pos] = self._code(self._ws_codes, row.get("workspaceId"))
+                table.kb_code[pos] = self._code(self._kb_codes, row.get("knowledgeBaseId"))
+                table.uri_code[pos] = self._code(self._uri_codes, row.get("uri"))
+                table.private[pos] = bool(row.get("private", False))
+                table.live[pos] = True
+                table.rows.append(row)
+                table.pk_map[pk] = pos
+        return row
+
+    async def clean_table(self, table_name: str, where: Dict[str, Any]) -> bool:
+        """Delete every row matching all ``where`` items; True if any row went (pgvector.py:452-473)."""
+        try:
+            table = self.get_model(table_name)
+        except NotImplementedError:
+            return await self.delegate.clean_table(table_name=table_name, where=where)
+        except ValueError:
+            if table_name in ("Graph", "Nodes"):  # graph tables are not held here
+                if self.delegate is not None:
+                    return await self.delegate.clean_table(table_name=table_name, where=where)
+                return False
+            raise
+        unknown = [k for k in where if k not in table.colset]
+        if unknown:
+            raise AttributeError(f"table {table_name} has no column {unknown[0]!r}")
+        async with self._lock:
+            hit = [
+                pos
+                for pos, row in enumerate(table.rows)
+                if row is not None and all(row.get(k) == v for k, v in where.items())
+            ]
+            if hit:
+                for pos in hit:
+                    row = table.rows[pos]
+                    table.pk_map.pop(tuple(row.get(c) for c in table.pk), None)
+                    table.rows[pos] = None
+                    table.live[pos] = False
+                if table.index is not None:
+                    await asyncio.to_thread(table.index.set_deleted, np.asarray(hit, dtype=np.int64), True)
+        return len(hit) != 0
+
+    # -- query -------------------------------------------------------------------------------------
+    def _row_filter(self, table: _Table, workspace_id, knowledge_base_id, uri_list, require_access):
+        """-> (group_filter, mask words or None, empty?)  mirroring the WHERE clauses of pgvector.py:573-580."""
+        n = len(table.rows)
+        group_filter = -1
+        keep = None
+        has = table.colset.__contains__
+        use_ws = bool(workspace_id) and has("workspaceId")
+        use_kb = bool(knowledge_base_id) and has("knowledgeBaseId")
+        if use_ws and use_kb:
+            code = self._group_codes.get((workspace_id, knowledge_base_id))
+            if code is None:
+                return -1, None, True
+            group_filter = code
+        elif use_ws or use_kb:
+            codes, arr, key = (self._ws_codes, table.ws_code, workspace_id) if use_ws else (self._kb_codes, table.kb_code, knowledge_base_id)
+            code = codes.get(key)
+            if code is None:
+                return -1, None, True
+            keep = arr[:n] == code
+        if uri_list and has("uri"):
+            wanted = [self._uri_codes[u] for u in uri_list if u in self._uri_codes]
+            k2 = np.isin(table.uri_code[:n], np.asarray(wanted, dtype=np.int32))
+            keep = k2 if keep is None else keep & k2
+        if require_access is not None and has("private"):
+            k3 = table.private[:n] == (require_access == "private")
+            keep = k3 if keep is None else keep & k3
+        if keep is None:
+            return group_filter, None, False
+        if not keep.any():
+            return group_filter, None, True
+        bits = np.packbits(keep, bitorder="little")
+        pad = (-len(bits)) % 4
+        if pad:
+            bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
+        return group_filter, bits.view(np.uint32), False
+
+    async def query(
+        self,
+        query: Union[str, List[str]],
+        workspace_id: str,
+        knowledge_base_id: str,
+        table_name: str,
+        topk: Optional[int] = None,
+        topn: Optional[int] = None,
+        uri_list: Optional[List[str]] = None,
+        require_access: Optional[Literal["private", "public"]] = None,
+        columns_to_select: Optional[List[str]] = None,
+        distance_threshold: Optional[float] = None,
+        rerank: bool = False,
+    ) -> List[dict]:
+        """``PGVector.query`` (pgvector.py:520-604): distance = LEAST over the query strings'
+        embeddings of the cosine distance; filters; ``distance < threshold`` (0.8 whenever the
+        argument is falsy); ascending; first ``topk`` (10 by default)."""
+        if isinstance(query, str):
+            query = [query]
+        topk = topk if topk else DEFAULT_QUERY_TOP_K
+        topn = topn if topn else DEFAULT_QUERY_TOP_N
+        distance_threshold = distance_threshold if distance_threshold else DEFAULT_DISTANCE_THRESHOLD
+        if topn > topk:
+            raise ValueError(f"topn ({topn}) must be <= topk ({topk})")
+        table = self.get_model(table_name)
+        if not table.has_vector:
+            raise AttributeError(f"table {table_name} has no vector column")
+        if columns_to_select is None:
+            columns_to_select = [c for c in table.columns if c != "vector"]
+        start = time.perf_counter()
+        q_embs = await self.embedding_func(query)
+        q = np.asarray([self._to_list(e) for e in q_embs], dtype=np.float32)
+        if q.ndim != 2 or q.shape[0] == 0:
+            return []
+
+        scored: List[dict] = []
+        if table.index is not None and len(table.rows):
+            group_filter, mask, empty = self._row_filter(table, workspace_id, knowledge_base_id, uri_list, require_access)
+            if not empty:
+                pairs = await asyncio.to_thread(self._search, table, q, int(topk), group_filter, mask, float(distance_threshold))
+                want_vec = "vector" in columns_to_select
+                vecs = None
+                if want_vec and pairs:
+                    vecs = await asyncio.to_thread(table.index.gather, np.asarray([p for p, _ in pairs], dtype=np.int64))
+                for j, (pos, dist) in enumerate(pairs):
+                    row = table.rows[pos]
+                    payload = {}
+                    for col in columns_to_select:
+                        if col == "vector":
+                            payload[col] = StoredVector(vecs[j].tolist())
+                        elif col in table.colset:
+                            payload[col] = row.get(col)
+                    payload["distance"] = dist
+                    scored.append(payload)
+        logger.info(f"[query] Retrieved {len(scored)} records from '{table_name}', elapsed={time.perf_counter() - start:.3f}s")
+        return scored
+
+    def _search(self, table: _Table, q: np.ndarray, topk: int, group_filter: int, mask, threshold: float):
+        """Blocking part of ``query``: one fused LEAST-fold search (or several for > 8 embeddings)."""
+        index = table.index
+        m = q.shape[0]
+        if m <= _MAX_FOLD:
+            dist, ids, cnt = index.search(q, k=topk, fold=m, group_filter=group_filter, row_mask=mask, max_distance=threshold)
+            c = int(cnt[0])
+            return [(int(ids[0][i]), float(dist[0][i])) for i in range(c)]
+        # more embeddings than one launch folds: every row of the final top-k is inside the top-k of
+        # the group of embeddings that realises its minimum, so per-row minima over the groups' lists
+        # followed by a sort is exact
+        best: Dict[int, float] = {}
+        for s in range(0, m, _MAX_FOLD):
+            part = q[s : s + _MAX_FOLD]
+            dist, ids, cnt = index.search(part, k=topk, fold=part.shape[0], group_filter=group_filter, row_mask=mask,
+                                          max_distance=threshold)
+            for i in range(int(cnt[0])):
+                pos, d = int(ids[0][i]), float(dist[0][i])
+                if pos not in best or d < best[pos]:
+                    best[pos] = d
+        return sorted(best.items(), key=lambda t: (t[1], t[0]))[:topk]
+
+    async def query_by_keys(
+        self,
+        key_value: List[str],
+        workspace_id: str,
+        knowledge_base_id: str,
+        table_name: str,
+        key_column: str = "documentKey",
+        columns_to_select: Optional[List[str]] = None,
+        additional_data_to_select: Optional[Dict[str, Any]] = None,
+        additional_where_clause_list: Optional[Any] = None,
+        order_by: Optional[List[Any]] = None,
+        limit: Optional[int] = None,
+    ) -> List[dict]:
+        """Rows by key (pgvector.py:606-660).  Selecting ``"vector"`` returns the stored embedding
+        (widened to float) as a ``StoredVector``."""
+        if additional_data_to_select is not None or additional_where_clause_list is not None or order_by is not None:
+            if self.delegate is not None:
+                return await self.delegate.query_by_keys(
+                    key_value, workspace_id, knowledge_base_id, table_name, key_column, columns_to_select,
+                    additional_data_to_select, additional_where_clause_list, order_by, limit)
+            raise NotImplementedError("SQL-expression arguments of query_by_keys need a delegate store")
+        table = self.get_model(table_name)
+        if key_column not in table.colset:
+            raise AttributeError(f"table {table_name} has no column {key_column!r}")
+        if columns_to_select is None:
+            columns_to_select = [c for c in table.columns if c != "vector"]
+        wanted = set(key_value) if key_value else None
+        use_ws = bool(workspace_id) and "workspaceId" in table.colset
+        use_kb = bool(knowledge_base_id) and "knowledgeBaseId" in table.colset
+        hits: List[int] = []
+        for pos, row in enumerate(table.rows):
+            if row is None:
+                continue
+            if wanted is not None and row.get(key_column) not in wanted:
+                continue
+            if use_ws and row.get("workspaceId") != workspace_id:
+                continue
+            if use_kb and row.get("knowledgeBaseId") != knowledge_base_id:
+                continue
+            hits.append(pos)
+            if limit is not None and len(hits) >= limit:
+                break
+        vecs = None
+        if "vector" in columns_to_select and table.has_vector and hits and table.index is not None:
+            vecs = await asyncio.to_thread(table.index.gather, np.asarray(hits, dtype=np.int64))
+        out: List[dict] = []
+        for j, pos in enumerate(hits):
+            row = table.rows[pos]
+            rec = {}
+            for col in columns_to_select:
+                if col == "vector" and table.has_vector:
+                    rec[col] = StoredVector(vecs[j].tolist()) if vecs is not None else None
+                elif col in table.colset:
+                    rec[col] = row.get(col)
+            out.append(rec)
+        return out
+
+    async def get_existing_document_keys(self, uri: str, workspace_id: str, knowledge_base_id: str, table_name: str) -> List[str]:
+        """``documentKey`` of every row with this uri / workspace / knowledge base (pgvector.py:662-683)."""
+        table = self.get_model(table_name)
+        return [
+            row.get("documentKey")
+            for row in table.rows
+            if row is not None
+            and row.get("uri") == uri
+            and row.get("workspaceId") == workspace_id
+            and row.get("knowledgeBaseId") == knowledge_base_id
+            and row.get("documentKey")
+        ]
+
+    async def get_table(self, table_name: str) -> List[dict]:
+        """Every live row with every column, vectors as lists (pgvector.py:685-702)."""
+        table = self.get_model(table_name)
+        live = [pos for pos, row in enumerate(table.rows) if row is not None]
+        vecs = None
+        if table.has_vector and table.index is not None and live:
+            vecs = await asyncio.to_thread(table.index.gather, np.asarray(live, dtype=np.int64))
+        out = []
+        for j, pos in enumerate(live):
+            rec = {col: table.rows[pos].get(col) for col in table.columns if col != "vector"}
+            if table.has_vector:
+                rec["vector"] = vecs[j].tolist() if vecs is not None else None
+            out.append(rec)
+        return out
+
+    # -- the full distance column (cross-language search) ------------------------------------------
+    async def query_distance_column(self, embeddings, workspace_id: str, knowledge_base_id: str,
+                                    table_name: str = "Items", columns_to_select: Optional[List[str]] = None,
+                                    column_name: str = "search_sentence_cosine_distance") -> List[dict]:
+        """Every row of one knowledge base with ``LEAST_i(vector <=> e_i)`` as an extra column: what
+        ``cross_language_search`` selects through ``additional_data_to_select``
+        (``src/hirag_prod/cross_language_search/search_service.py:100-113``), without ordering or limit."""
+        table = self.get_model(table_name)
+        if columns_to_select is None:
+            columns_to_select = [c for c in table.columns if c != "vector"]
+        q = np.asarray([self._to_list(e) for e in embeddings], dtype=np.float32)
+        if table.index is None or not len(table.rows) or q.size == 0:
+            return []
+        col = None
+        for s in range(0, q.shape[0], _MAX_FOLD):
+            part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_FOLD])
+            col = part if col is None else np.fmin(col, part)  # fmin: NaN only if both are NaN
+        out = []
+        for pos, row in enumerate(table.rows):
+            if row is None:
+                continue
+            if workspace_id and row.get("workspaceId") != workspace_id:
+                continue
+            if knowledge_base_id and row.get("knowledgeBaseId") != knowledge_base_id:
+                continue
+            rec = {c: row.get(c) for c in columns_to_select if c in table.colset and c != "vector"}
+            d = float(col[pos])
+            rec[column_name] = None if math.isnan(d) else d
+            out.append(rec)
+        return out
+
+    # -- delegated (graph side, not on the dense-retrieval path) -------------------------------------
+    def __getattr__(self, name):
+        if name in ("upsert_graph", "query_node", "pagerank_top_chunks_with_reset", "upsert_file_from_metadata"):
+            delegate = self.__dict__.get("delegate")
+            if delegate is not None:
+                return getattr(delegate, name)
+            raise NotImplementedError(
+                f"{name} belongs to the reference's graph tables, which this store does not hold; "
+                "create it with delegate=<PGVector instance> to forward such calls"
+            )
+        raise AttributeError(name)
+
+    async def health_check(self) -> Dict[str, Any]:
+        from . import _lib
+
+        return {
+            "vdb": _lib.device_count() > 0,
+            "rows": {name: int(t.live[: len(t.rows)].sum()) for name, t in self.tables.items()},
+        }
+
+    def close(self) -> None:
+        for table in self.tables.values():
+            if table.index is not None and hasattr(table.index, "close"):
+                table.index.close()
+                table.index = None
+
+
+__all__ = ["BaseVDB", "HipVectorStore", "StoredVector"]

@@ -1,0 +1,72 @@
+"""Test double for ``HvsIndex`` built on the oracle, so the store's HOST logic can run on CPU.
+
+Only tests construct it (through ``HipVectorStore(index_factory=...)``); the product's default
+factory is ``HvsIndex`` and needs the GPU.
+"""
+
+import math
+
+import numpy as np
+
+from oracle import pgvector_oracle as po
+
+
+class OracleIndex:
+    def __init__(self, dim, dtype, device=0):
+        self.dim, self.dtype = dim, dtype
+        self.rows = np.zeros((0, dim), dtype=np.float32)
+        self.groups = np.zeros(0, dtype=np.int32)
+        self.deleted = np.zeros(0, dtype=bool)
+
+    def __len__(self):
+        return self.rows.shape[0]
+
+    def add(self, rows, ids=None, group_codes=None):
+        first = len(self)
+        rows = np.asarray(rows, dtype=np.float32)
+        self.rows = np.concatenate([self.rows, rows])
+        g = np.zeros(rows.shape[0], np.int32) if group_codes is None else np.asarray(group_codes, np.int32)
+        self.groups = np.concatenate([self.groups, g])
+        self.deleted = np.concatenate([self.deleted, np.zeros(rows.shape[0], bool)])
+        return first, len(self)
+
+    def set_deleted(self, positions, deleted=True):
+        self.deleted[np.asarray(positions, dtype=np.int64)] = deleted
+
+    def _keep(self, group_filter, row_mask):
+        keep = ~self.deleted
+        if group_filter >= 0:
+            keep &= self.groups == group_filter
+        if row_mask is not None:
+            bits = np.unpackbits(np.asarray(row_mask, dtype=np.uint32).view(np.uint8), bitorder="little")
+            keep &= bits[: len(self)].astype(bool)
+        return keep
+
+    def search(self, queries, k=10, fold=1, group_filter=-1, row_mask=None, max_distance=math.inf, **kw):
+        q = np.atleast_2d(np.asarray(queries, dtype=np.float32))
+        nq = q.shape[0] // fold
+        dist = np.full((nq, k), np.inf, dtype=np.float32)
+        ids = np.full((nq, k), -1, dtype=np.int64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        keep = self._keep(group_filter, row_mask)
+        for i in range(nq):
+            idx, d = po.query(self.rows, q[i * fold : (i + 1) * fold], k=k,
+                              threshold=None if math.isinf(max_distance) else max_distance, keep=keep,
+                              storage=self.dtype)
+            cnt[i] = len(idx)
+            ids[i, : len(idx)] = idx
+            dist[i, : len(idx)] = d
+        return dist, ids, cnt
+
+    def distances(self, queries, row_begin=0, row_end=-1):
+        q = np.atleast_2d(np.asarray(queries, dtype=np.float32))
+        rows_s = po.round_storage(self.rows, self.dtype)
+        q_s = po.round_storage(q, self.dtype)
+        d = np.stack([po.cosine_distance(rows_s, q_s[i]) for i in range(q.shape[0])])
+        return po.least_fold(d).astype(np.float32)
+
+    def gather(self, positions):
+        return po.round_storage(self.rows[np.asarray(positions, dtype=np.int64)], self.dtype).astype(np.float32)
+
+    def close(self):
+        pass

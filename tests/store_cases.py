@@ -1,0 +1,185 @@
+"""Scenarios for the ``BaseVDB`` drop-in, run on CPU with the oracle-backed test index and on the GPU
+with the real one.  They read like the tests the reference would hold for ``PGVector`` if it had
+any for this path (it has none: its storage tests need a live PostgreSQL)."""
+
+import asyncio
+import hashlib
+import math
+
+import numpy as np
+
+from oracle import pgvector_oracle as po
+
+DIM = 64
+
+
+def embed_text(text: str, dim: int = DIM) -> np.ndarray:
+    """Deterministic stand-in for the embedding service; empty text embeds to zeros, as
+    ``EmbeddingService.create_embeddings`` does (``_llm.py:765-768``, pinned by ``tests/test_llm.py:99-113``)."""
+    if not text:
+        return np.zeros(dim, dtype=np.float64)
+    seed = int.from_bytes(hashlib.md5(text.encode()).digest()[:8], "little")
+    return np.random.default_rng(seed).standard_normal(dim)
+
+
+def make_embedding_func(dim: int = DIM):
+    async def embedding_func(texts):
+        return np.stack([embed_text(t, dim) for t in texts])
+
+    return embedding_func
+
+
+def chunk_props(i, ws="ws1", kb="kb1", uri=None, private=False):
+    return {
+        "documentKey": f"chunk-{ws}-{kb}-{i}",
+        "knowledgeBaseId": kb,
+        "workspaceId": ws,
+        "text": f"text {ws} {kb} {i}",
+        "fileName": f"file{i % 3}.pdf",
+        "uri": uri or f"s3://bucket/file{i % 3}.pdf",
+        "private": private,
+        "documentId": f"doc-{i % 3}",
+        "chunkIdx": i,
+        "not_a_column": "dropped",
+    }
+
+
+def same_hits(got_keys, exp_keys, exp_dist, got_dist=None):
+    """Equal hit lists, up to swaps between entries whose oracle distances tie within 1e-6 (the
+    parity bar for ids); distances within 1e-5."""
+    got_keys, exp_keys = list(got_keys), list(exp_keys)
+    assert len(got_keys) == len(exp_keys), (got_keys, exp_keys)
+    if got_dist is not None:
+        np.testing.assert_allclose(got_dist, exp_dist, atol=1e-5)
+    for p, (g, e) in enumerate(zip(got_keys, exp_keys)):
+        if g != e:
+            assert g in exp_keys, f"unexpected hit {g}"
+            assert abs(exp_dist[exp_keys.index(g)] - exp_dist[p]) <= 1e-6, f"rank {p}: {g} vs {e}"
+
+
+def expected_hits(texts, keep, queries, k, thr, storage, dim=DIM):
+    rows = np.stack([embed_text(t, dim) for t in texts]).astype(np.float32)
+    q = np.stack([embed_text(t, dim) for t in queries]).astype(np.float32)
+    return po.query(rows, q, k=k, threshold=thr, keep=keep, storage=storage)
+
+
+async def scenario_basic(store, storage):
+    await store._init_vdb(embedding_dimension=DIM)
+    n = 200
+    props = [chunk_props(i, ws="ws1" if i % 2 else "ws2", private=(i % 5 == 0)) for i in range(n)]
+    texts = [p["text"] for p in props]
+    texts[7] = ""  # embeds to zeros: never returned
+    rows = await store.upsert_texts(texts, props, "Chunks")
+    assert len(rows) == n and "not_a_column" not in rows[0] and "updatedAt" in rows[0]
+    # first write wins: same keys, different text
+    again = await store.upsert_texts(["changed"] * 3, props[:3], "Chunks")
+    assert len(again) == 3
+    got = await store.query_by_keys([props[0]["documentKey"]], "ws2", "kb1", "Chunks")
+    assert len(got) == 1 and got[0]["text"] == props[0]["text"]
+
+    ws = np.array([p["workspaceId"] for p in props])
+    private = np.array([p["private"] for p in props])
+    uris = np.array([p["uri"] for p in props])
+
+    # default call: k=10, threshold 0.8, all non-vector columns
+    res = await store.query("text ws1 kb1 11", "ws1", "kb1", "Chunks")
+    idx, dist = expected_hits(texts, ws == "ws1", ["text ws1 kb1 11"], 10, 0.8, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+    assert res[0]["documentKey"] == props[11]["documentKey"] and res[0]["distance"] < 1e-3
+    assert "vector" not in res[0] and "text" in res[0] and isinstance(res[0]["distance"], float)
+
+    # three query strings folded by LEAST, wide threshold, selected columns
+    qs = ["text ws1 kb1 11", "text ws1 kb1 13", "something else"]
+    res = await store.query(qs, "ws1", "kb1", "Chunks", topk=20, topn=5, distance_threshold=1.2,
+                            columns_to_select=["documentKey", "uri", "bogus"])
+    idx, dist = expected_hits(texts, ws == "ws1", qs, 20, 1.2, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist)
+    assert set(res[0]) == {"documentKey", "uri", "distance"}
+
+    # uri_list + require_access + only one of workspace/kb
+    res = await store.query("text ws2 kb1 4", "", "kb1", "Chunks", topk=15, distance_threshold=1.5,
+                            uri_list=["s3://bucket/file1.pdf", "s3://nowhere"], require_access="public")
+    keep = (uris == "s3://bucket/file1.pdf") & ~private
+    idx, dist = expected_hits(texts, keep, ["text ws2 kb1 4"], 15, 1.5, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist)
+    res = await store.query("text ws2 kb1 4", "ws2", "kb1", "Chunks", topk=15, distance_threshold=1.5, require_access="private")
+    idx, dist = expected_hits(texts, (ws == "ws2") & private, ["text ws2 kb1 4"], 15, 1.5, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist)
+
+    # unknown workspace: empty; zero-vector query (empty string): empty
+    assert await store.query("x", "nope", "kb1", "Chunks") == []
+    assert await store.query("", "ws1", "kb1", "Chunks") == []
+
+    # errors as the reference raises them
+    for bad in (
+        lambda: store.query("x", "ws1", "kb1", "NoSuchTable"),
+        lambda: store.query("x", "ws1", "kb1", "Chunks", topk=3, topn=5),
+        lambda: store.upsert_texts(["a"], [], "Chunks"),
+    ):
+        try:
+            await bad()
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("expected ValueError")
+
+    # stored vectors come back rounded to the column type, with to_list()
+    got = await store.query_by_keys([props[3]["documentKey"], props[5]["documentKey"]], "ws1", "kb1", "Chunks",
+                                    columns_to_select=["documentKey", "vector"])
+    assert len(got) == 2
+    for g in got:
+        i = int(g["documentKey"].rsplit("-", 1)[1])
+        np.testing.assert_array_equal(np.array(g["vector"].to_list(), dtype=np.float32),
+                                      po.round_storage(embed_text(texts[i]), storage).astype(np.float32))
+
+    # existing keys of one file, then delete that file's rows
+    keys = await store.get_existing_document_keys("s3://bucket/file0.pdf", "ws1", "kb1", "Chunks")
+    assert sorted(keys) == sorted(p["documentKey"] for p in props if p["uri"].endswith("file0.pdf") and p["workspaceId"] == "ws1")
+    assert await store.clean_table("Chunks", {"uri": "s3://bucket/file0.pdf", "workspaceId": "ws1"}) is True
+    assert await store.clean_table("Chunks", {"uri": "s3://bucket/file0.pdf", "workspaceId": "ws1"}) is False
+    res = await store.query("text ws1 kb1 11", "ws1", "kb1", "Chunks", topk=50, distance_threshold=1.9)
+    assert all(not r["uri"].endswith("file0.pdf") for r in res)
+    keep = (ws == "ws1") & ~np.char.endswith(uris, "file0.pdf")
+    idx, dist = expected_hits(texts, keep, ["text ws1 kb1 11"], 50, 1.9, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist)
+    # a deleted key can be inserted again
+    again = await store.upsert_texts([texts[3 if props[3]["uri"].endswith("file0.pdf") else 9]],
+                                     [props[3 if props[3]["uri"].endswith("file0.pdf") else 9]], "Chunks")
+    assert len(again) == 1
+
+    # the full distance column of cross-language search
+    col = await store.query_distance_column([embed_text("text ws2 kb1 4"), embed_text("text ws2 kb1 8")], "ws2", "kb1", "Chunks",
+                                            columns_to_select=["documentKey"])
+    assert len(col) == sum(1 for p in props if p["workspaceId"] == "ws2")
+    by_key = {c["documentKey"]: c["search_sentence_cosine_distance"] for c in col}
+    assert by_key[props[4]["documentKey"]] < 1e-3 and by_key[props[8]["documentKey"]] < 1e-3
+
+    # Files table: metadata only
+    f = {"documentKey": "file-1", "knowledgeBaseId": "kb1", "workspaceId": "ws1", "text": "", "fileName": "a.pdf",
+         "uri": "s3://bucket/a.pdf", "junk": 1}
+    row = await store.upsert_file(f)
+    assert "junk" not in row
+    assert await store.clean_table("Files", {"documentKey": "file-1"}) is True
+    assert await store.clean_table("Graph", {"documentId": "x"}) is False
+    try:
+        store.upsert_graph
+    except NotImplementedError:
+        pass
+    else:
+        raise AssertionError("graph calls must not be silently accepted")
+
+
+async def scenario_many_embeddings(store, storage):
+    """More query variants than one launch folds (9 > 8): still the exact LEAST."""
+    await store._init_vdb(embedding_dimension=DIM)
+    props = [chunk_props(i) for i in range(120)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts, props, "Chunks")
+    qs = [f"variant {j}" for j in range(9)]
+    res = await store.query(qs, "ws1", "kb1", "Chunks", topk=12, distance_threshold=1.9)
+    idx, dist = expected_hits(texts, None, qs, 12, 1.9, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+
+
+def run(coro):
+    return asyncio.run(coro)

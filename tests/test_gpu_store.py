@@ -1,0 +1,71 @@
+"""GPU tier: the BaseVDB drop-in end to end on the real HIP index, and a small-knowledge-base
+workload of the shape the reference's 2wiki benchmark produces (its data are not in the tree)."""
+
+import numpy as np
+import pytest
+
+from oracle import pgvector_oracle as po
+from tests import store_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _store(vector_type, dim=None):
+    import hirag_prod_amd.store as st
+
+    return st.HipVectorStore.create(store_cases.make_embedding_func(dim or store_cases.DIM), vector_type=vector_type)
+
+
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32"), ("bf16", "bf16")])
+def test_store_basic_gpu(vector_type, storage):
+    s = _store(vector_type)
+    store_cases.run(store_cases.scenario_basic(s, storage))
+    s.close()
+
+
+def test_store_many_embeddings_gpu():
+    s = _store("halfvec")
+    store_cases.run(store_cases.scenario_many_embeddings(s, "f16"))
+    s.close()
+
+
+def test_small_kb_workload():
+    """8192 chunks + 32768 triplets, D = 1536, halfvec, 3 query variants, workspace/kb filter,
+    threshold 0.8: both scans of one user query (Chunks, Triplets) against the float64 oracle."""
+    dim = 1536
+    s = _store("halfvec", dim)
+
+    async def go():
+        await s._init_vdb(embedding_dimension=dim)
+        rng = np.random.default_rng(1)
+        nc, nt = 8192, 32768
+        # texts are only keys of the deterministic embedder; half the rows sit in another knowledge base
+        chunk_props = [store_cases.chunk_props(i, kb="kb1" if i % 2 else "kb2") for i in range(nc)]
+        chunk_texts = [p["text"] for p in chunk_props]
+        await s.upsert_texts(chunk_texts, chunk_props, "Chunks")
+        trip_props = [
+            {"source": f"ent-{i}", "target": f"ent-{i + 1}", "description": f"ent-{i} relates to ent-{i + 1} ({i % 7})",
+             "knowledgeBaseId": "kb1" if i % 2 else "kb2", "workspaceId": "ws1", "fileName": "f.pdf", "uri": "u", "documentId": "d"}
+            for i in range(nt)
+        ]
+        trip_texts = [p["description"] for p in trip_props]
+        await s.upsert_texts(trip_texts, trip_props, "Triplets")
+        for t in range(5):
+            # a query close to a stored chunk so that some rows pass the 0.8 threshold
+            base = int(rng.integers(0, nc // 2)) * 2 + 1
+            qs = [chunk_texts[base], f"paraphrase {t}", f"translation {t}"]
+            res = await s.query(qs, "ws1", "kb1", "Chunks", topk=10, topn=5)
+            keep = np.array([p["knowledgeBaseId"] == "kb1" for p in chunk_props])
+            idx, dist = store_cases.expected_hits(chunk_texts, keep, qs, 10, 0.8, "f16", dim)
+            store_cases.same_hits([r["documentKey"] for r in res], [chunk_props[i]["documentKey"] for i in idx], dist,
+                                  [r["distance"] for r in res])
+            assert len(res) >= 1 and res[0]["documentKey"] == chunk_props[base]["documentKey"]
+            tq = [trip_texts[base], f"other {t}"]
+            res = await s.query(tq, "ws1", "kb1", "Triplets", topk=10, topn=5,
+                                columns_to_select=["source", "target", "description", "fileName"])
+            keep = np.array([p["knowledgeBaseId"] == "kb1" for p in trip_props])
+            idx, dist = store_cases.expected_hits(trip_texts, keep, tq, 10, 0.8, "f16", dim)
+            store_cases.same_hits([r["description"] for r in res], [trip_props[i]["description"] for i in idx], dist)
+
+    store_cases.run(go())
+    s.close()

@@ -1,0 +1,37 @@
+"""CPU tier: host logic of the BaseVDB drop-in (metadata, filters, defaults, errors), with the
+oracle-backed test index standing in for the GPU index."""
+
+import pytest
+
+from tests import store_cases
+from tests.fake_index import OracleIndex
+
+
+def _store(vector_type):
+    import hirag_prod_amd.store as st
+
+    return st.HipVectorStore.create(store_cases.make_embedding_func(), vector_type=vector_type,
+                                    index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device))
+
+
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
+def test_store_basic(vector_type, storage):
+    store_cases.run(store_cases.scenario_basic(_store(vector_type), storage))
+
+
+def test_store_many_embeddings():
+    store_cases.run(store_cases.scenario_many_embeddings(_store("halfvec"), "f16"))
+
+
+def test_store_is_a_basevdb_and_refuses_without_gpu():
+    import hirag_prod_amd as hvs
+    import hirag_prod_amd.store as st
+
+    s = st.HipVectorStore.create(store_cases.make_embedding_func())
+    assert isinstance(s, st.BaseVDB)
+    if hvs.device_count() == 0:
+        # the product path has no CPU fallback: creating the index must fail loudly
+        with pytest.raises(hvs.HvsError):
+            store_cases.run(s._init_vdb(embedding_dimension=8))
+    with pytest.raises(ValueError):
+        st.HipVectorStore(None, vector_type="int8")
