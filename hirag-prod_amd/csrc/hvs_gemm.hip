@@ -41,6 +41,7 @@ struct SearchParams {
     uint64_t *cand;   // [gridDim.x, BM / fold, cap]
     uint64_t *partial;  // [nq_out, S, k]
     int QT, S;
+    int QG;         // q-tiles per XCD group (0 = one XCD per split)
     int64_t T;      // corpus tiles in [row_begin, row_end)
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
 };
@@ -108,7 +109,13 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
     // block -> (query tile, corpus split); blocks that share a split sit on one XCD (b % 8) so that
     // they stream the same corpus tiles through one L2
     int qt, s;
-    if ((p.S & 7) == 0) {
+    if (p.QG > 0) {
+        // XCD x serves q-tile group x % NQG and every SG-th split starting at x / NQG
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int nqg = p.QT / p.QG, sg = 8 / nqg;
+        qt = (xcd % nqg) * p.QG + t % p.QG;
+        s = xcd / nqg + sg * (t / p.QG);
+    } else if ((p.S & 7) == 0) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         qt = t % p.QT;
         s = xcd + 8 * (t / p.QT);
@@ -339,6 +346,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (S >= 8) S = S / 8 * 8;
     if (S < 1) S = 1;
     p.S = S;
+    p.QG = 0;
+    if (const char *e = getenv("HVS_QG")) {
+        const int qg = atoi(e);
+        if (qg > 0 && p.QT % qg == 0 && 8 % (p.QT / qg) == 0 && (S % (8 / (p.QT / qg))) == 0 && (p.QT * S) % 8 == 0) p.QG = qg;
+    }
     const int grid = p.QT * S;
     const int groups_per_tile = BM / pf;
 
