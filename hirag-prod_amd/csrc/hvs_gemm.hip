@@ -8,9 +8,10 @@
 // filter bit, running argmin) are per-lane scalars and folding consecutive query embeddings (LEAST)
 // is a min over adjacent accumulator registers.
 //
-// The K loop streams 32-float slices of both operands through a double-buffered LDS image
-// (global -> VGPR -> ds_write_b128, XOR-swizzled so that the ds_read_b128 fragment reads are
-// conflict-free); loads for step g+1 are in flight while step g's 64 MFMAs per wave run.
+// The K loop streams 32-float slices of both operands through a double-buffered LDS image filled by
+// LDS-DMA (buffer_load_dwordx4 ... lds, XOR swizzle applied on the source address so that the
+// ds_read_b128 fragment reads are conflict-free); the DMA of step g+1 is in flight while step g's
+// 64 MFMAs per wave run.
 //
 // Search never writes the score matrix: the epilogue of every 128 x 128 tile compares each score
 // with the query's current admission bound tau (the k-th best distance seen so far by this block)
@@ -22,9 +23,10 @@
 // search
 // ---------------------------------------------------------------------------------------------
 struct SearchParams {
-    const float *A;      // prepared queries [nA, ld]
+    const float *A;      // prepared queries [nA, lda], lda a multiple of BK, pad columns zero
     const float *q_inv;  // [nA]
-    int nA;              // nq_out * fold
+    int nA;              // nq_out * FOLD
+    int lda;
     const float *X;      // corpus [*, ld]
     const float *inv_norm;
     const int32_t *groups;
@@ -33,17 +35,16 @@ struct SearchParams {
     int32_t group_filter;
     int64_t row_begin, row_end;
     int ld, nks;
-    int fold;    // 1, 2 or 4 (embeddings folded by LEAST, consecutive A rows)
     int nq_out;  // output queries
     int k;
     float thr;
-    int cap;          // capacity of one candidate array
-    uint64_t *cand;   // [gridDim.x, BM / fold, cap]
+    int cap;            // capacity of one candidate array
+    uint64_t *cand;     // [gridDim.x, BM / FOLD, cap]
     uint64_t *partial;  // [nq_out, S, k]
     int QT, S;
-    int QG;         // q-tiles per XCD group (0 = one XCD per split)
     int64_t T;      // corpus tiles in [row_begin, row_end)
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
+    int dbg;        // timing experiments only (HVS_DBG): 1 no DMA, 4 no barrier, 8 no epilogue
 };
 
 // One wave ranks the candidate array of one query, keeps the best `keep`, writes them in ascending
@@ -91,31 +92,35 @@ __device__ __forceinline__ int rank_select(const uint64_t *src, int cnt, int kee
     return newcnt;
 }
 
-template <int FOLD>
-__global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
+// Lower bound on dot * inv_row that a row needs for its distance to be below tau, loosened so that
+// it never rejects a row the exact fp32 test (hvs_cos_dist(...) < tau) would accept.
+__device__ __forceinline__ float prefilter_bound(float tau, float q_inv) {
+    const float t = ((1.0f - tau) - 4e-7f) / q_inv;
+    return t - fabsf(t) * 4e-7f;
+}
+
+template <int FOLD, int BK>
+__global__ __launch_bounds__(GT, BK == 32 ? 2 : 3) void mfma_search_kernel(SearchParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
+    constexpr int STAGE = STAGE_FLOATS(BK);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *stages = reinterpret_cast<float *>(smem);                          // 2 * STAGE_FLOATS
-    float *tau_lds = stages + 2 * STAGE_FLOATS;                               // [BM]
-    int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM]
-    float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM]
-    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(qinv_lds + BM);      // [4][CAND_MAX]
+    float *tau_lds = stages + 2 * STAGE;                               // [BM] per folded query
+    int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM] per folded query
+    float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM] per A row
+    float *bound_lds = qinv_lds + BM;                                         // [BM] per A row
+    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(bound_lds + BM);     // [4][CAND_MAX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5;
 
     // block -> (query tile, corpus split); blocks that share a split sit on one XCD (b % 8) so that
     // they stream the same corpus tiles through one L2
     int qt, s;
-    if (p.QG > 0) {
-        // XCD x serves q-tile group x % NQG and every SG-th split starting at x / NQG
-        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
-        const int nqg = p.QT / p.QG, sg = 8 / nqg;
-        qt = (xcd % nqg) * p.QG + t % p.QG;
-        s = xcd / nqg + sg * (t / p.QG);
-    } else if ((p.S & 7) == 0) {
+    if ((p.S & 7) == 0) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         qt = t % p.QT;
         s = xcd + 8 * (t / p.QT);
@@ -134,19 +139,28 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
         tau_lds[i] = p.thr;
         cnt_lds[i] = 0;
         const int64_t ar = a_row0 + i;
-        qinv_lds[i] = ar < p.nA ? p.q_inv[ar] : 0.0f;
+        const float qi = ar < p.nA ? p.q_inv[ar] : 0.0f;
+        qinv_lds[i] = qi;
+        bound_lds[i] = prefilter_bound(p.thr, qi);
     }
 
     f32x16 acc[2][2];
     zero_acc(acc);
-    TileRegs regs;
     const int64_t n_tiles = tile_hi - tile_lo;
     const int64_t total_steps = n_tiles * p.nks;
-    const int64_t a_last = p.nA - 1, b_last = p.row_end - 1;
-
+    TileSrc<BK> srcA, srcB;
+    {
+        const int64_t a_valid = p.nA - a_row0;
+        tile_src_init(srcA, p.A, a_row0, a_valid < BM ? (int)a_valid : BM, p.lda, tid);
+    }
+    auto init_b = [&](int64_t tile) {
+        const int64_t r0 = p.row_begin + tile * BN;
+        const int64_t valid = p.row_end - r0;
+        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld, tid);
+    };
     if (total_steps > 0) {
-        load_tiles(regs, p.A, a_row0, a_last, p.X, p.row_begin + tile_lo * BN, b_last, p.ld, 0, tid);
-        store_tiles(regs, stages, tid);
+        init_b(tile_lo);
+        dma_tiles<BK>(srcA, srcB, stages, 0, wave);
     }
     __syncthreads();
 
@@ -159,13 +173,14 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
         int64_t ntile = tile;
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
         const bool have_next = g + 1 < total_steps;
-        if (have_next)
-            load_tiles(regs, p.A, a_row0, a_last, p.X, p.row_begin + ntile * BN, b_last, p.ld, nks_next * BK, tid);
-
-        compute_step(acc, stages + cur * STAGE_FLOATS, wm, wn, lane);
+        const bool prefetch = have_next && !(p.dbg & 1);
+        if (prefetch && nks_next == 0) init_b(ntile);
+        compute_step<BK>(acc, stages + cur * STAGE, wm, wn, lane, prefetch, srcA, srcB, stages + (cur ^ 1) * STAGE,
+                         nks_next * BK, wave);
 
         if (ks == p.nks - 1) {
-            // ---- epilogue of tile `tile`: filter by tau, append survivors ----
+          if (!(p.dbg & 8)) {
+            // ---- epilogue of tile `tile`: prefilter against the bound, exact test for survivors ----
             const int64_t n_base = p.row_begin + tile * BN + wn * 64 + (lane & 31);
             int64_t rows2[2];
             bool ok2[2];
@@ -190,60 +205,70 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
                     const int a_loc = wm * 64 + mt * 32 + 8 * gq + 4 * h;  // A row of register 4*gq (+0..3)
-                    const f32x4 qi = *reinterpret_cast<const f32x4 *>(qinv_lds + a_loc);
+                    const f32x4 bnd = *reinterpret_cast<const f32x4 *>(bound_lds + a_loc);
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++) {
-                        float d[4];
+                        bool any = false;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) d[e] = hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]);
-                        if (FOLD == 2) {
-                            d[0] = fminf(d[0], d[1]);
-                            d[2] = fminf(d[2], d[3]);
-                        } else if (FOLD == 4) {
-                            d[0] = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                        }
+                        for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[e];
+                        any &= ok2[nt];
+                        if (__ballot(any)) {  // wave-uniform and rare once tau has tightened
+                            int av = a_loc;
+                            asm volatile("" : "+v"(av));  // keep this branch's address arithmetic inside it
+                            const f32x4 qi = *reinterpret_cast<const f32x4 *>(qinv_lds + av);
+                            float d[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e += FOLD) {
-                            const int ql = (a_loc + e) / FOLD;  // folded query, local to the tile
-                            if (ok2[nt] && d[e] < tau_lds[ql]) {
-                                int qv = ql;
-                                asm volatile("" : "+v"(qv));  // keep the address arithmetic inside this rare branch
-                                const int pos = atomicAdd(&cnt_lds[qv], 1);
-                                if (pos < p.cap) my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), (uint32_t)rows2[nt]);
-                                else *p.overflow = 1;
+                            for (int e = 0; e < 4; e++) d[e] = hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]);
+                            if (FOLD == 2) {
+                                d[0] = fminf(d[0], d[1]);
+                                d[2] = fminf(d[2], d[3]);
+                            } else if (FOLD == 4) {
+                                d[0] = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; e += FOLD) {
+                                const int qv = (av + e) / FOLD;  // folded query, local to the tile
+                                if (any && d[e] < tau_lds[qv]) {
+                                    const int pos = atomicAdd(&cnt_lds[qv], 1);
+                                    if (pos < p.cap) my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), (uint32_t)rows2[nt]);
+                                    else *p.overflow = 1;
+                                }
                             }
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the 8 groups from being interleaved (VGPR pressure)
                 }
             }
+          }
             zero_acc(acc);
         }
 
-        if (have_next) store_tiles(regs, stages + (cur ^ 1) * STAGE_FLOATS, tid);
-        __syncthreads();
+        if (!(p.dbg & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
 
         if (ks == p.nks - 1) {
-            // ---- compaction: arrays that could overflow during the next tile ----
+            // ---- compaction: arrays that could overflow during the next tile, and arrays that have grown
+            // enough for a fresher tau to pay (a stale tau admits ~count/k times too many survivors) ----
+            const int eager = p.k * 2 > 32 ? p.k * 2 : 32;
+            const int trigger = eager < p.cap - BN ? eager : p.cap - BN;
             for (int base = 0; base < groups_per_tile; base += 64) {
                 const int ql = base + lane;
-                const bool need = ql < groups_per_tile && cnt_lds[ql] > p.cap - BN;
+                // wave w owns the queries with (index & 3) == w: a static split, so no wave's decision
+                // depends on counters another wave is resetting at the same time
+                const bool need = ql < groups_per_tile && (ql & 3) == wave && cnt_lds[ql] > trigger;
                 uint64_t pending = __ballot(need);
-                // waves share the work round-robin over the set bits
-                int nth = 0;
                 while (pending) {
                     const int b = __ffsll((unsigned long long)pending) - 1;
                     pending &= pending - 1;
-                    if ((nth++ & 3) != wave) continue;
                     const int q = base + b;
                     int c = cnt_lds[q];
                     c = c > p.cap ? p.cap : c;
                     uint64_t kth;
                     uint64_t *arr = my_cand + (size_t)q * p.cap;
                     const int nc = rank_select(arr, c, p.k, arr, false, scratch, lane, &kth);
-                    if (lane == 0) {
-                        cnt_lds[q] = nc;
-                        if (nc == p.k) tau_lds[q] = hvs_unord((uint32_t)(kth >> 32));
+                    if (lane == 0) cnt_lds[q] = nc;
+                    if (nc == p.k) {
+                        const float tau = hvs_unord((uint32_t)(kth >> 32));
+                        if (lane == 0) tau_lds[q] = tau;
+                        if (lane < FOLD) bound_lds[q * FOLD + lane] = prefilter_bound(tau, qinv_lds[q * FOLD + lane]);
                     }
                 }
             }
@@ -265,6 +290,7 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
         uint64_t kth;
         rank_select(my_cand + (size_t)ql * p.cap, c, p.k, p.partial + ((size_t)qo * p.S + s) * p.k, true, scratch, lane, &kth);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -273,7 +299,7 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count);
 
-static size_t search_lds_bytes() { return (size_t)2 * STAGE_FLOATS * 4 + BM * 12 + (size_t)4 * CAND_MAX * 8; }
+static size_t search_lds_bytes(int bk) { return (size_t)2 * STAGE_FLOATS(bk) * 4 + BM * 16 + (size_t)4 * CAND_MAX * 8; }
 
 static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
 
@@ -282,15 +308,16 @@ bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k) {
     return idx->dtype == HVS_F32 && fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_MAX_K;
 }
 
-// copy query embeddings into groups of `pf` rows per output query (the last embedding repeated), with their norms
-__global__ void pad_fold_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, float *__restrict__ dst,
-                                float *__restrict__ dst_inv, int nq, int fold, int pf, int ld) {
+// A operand: groups of `pf` rows per output query (the last embedding repeated when fold < pf), row
+// pitch lda (a multiple of BK, pad columns zero), with the matching inverse norms.
+__global__ void build_a_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, float *__restrict__ dst,
+                               float *__restrict__ dst_inv, int fold, int pf, int ld, int lda) {
     const int row = blockIdx.x;  // destination row
     const int q = row / pf, j = row % pf;
     const int sj = j < fold ? j : fold - 1;
     const float *s = src + ((size_t)q * fold + sj) * ld;
-    float *d = dst + (size_t)row * ld;
-    for (int c = threadIdx.x; c < ld; c += blockDim.x) d[c] = s[c];
+    float *d = dst + (size_t)row * lda;
+    for (int c = threadIdx.x; c < lda; c += blockDim.x) d[c] = c < ld ? s[c] : 0.0f;
     if (threadIdx.x == 0) dst_inv[row] = src_inv[q * fold + sj];
 }
 
@@ -298,27 +325,24 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
                     int64_t *d_ids, int32_t *d_count) {
     const int pf = padded_fold(fold);
-    const float *A = d_q;
-    const float *A_inv = d_qinv;
     const int nA = nq * pf;
-    void *pad_ws = nullptr;
-    if (pf != fold) {
-        // slot 3 is free here: host staging in hvs_search uses it only for outputs/mask placed before this offset
-        const size_t bytes = (size_t)nA * idx->ld * 4 + (size_t)nA * 4 + 256;
-        HVS_HIP(hipMalloc(&pad_ws, bytes));
-        float *dst = (float *)pad_ws;
-        float *dst_inv = (float *)((char *)pad_ws + (((size_t)nA * idx->ld * 4 + 255) & ~(size_t)255));
-        pad_fold_kernel<<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, dst, dst_inv, nq, fold, pf, idx->ld);
-        HVS_HIP(hipGetLastError());
-        A = dst;
-        A_inv = dst_inv;
-    }
+    int bk = 32;
+    if (const char *e = getenv("HVS_BK")) bk = atoi(e) == 16 ? 16 : 32;
+    const int lda = (idx->ld + 31) / 32 * 32;
+    void *a_ws = nullptr;
+    const size_t a_bytes = ((size_t)nA * lda * 4 + 255) & ~(size_t)255;
+    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + (size_t)nA * 4, &a_ws));
+    float *A = (float *)a_ws;
+    float *A_inv = (float *)((char *)a_ws + a_bytes);
+    build_a_kernel<<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, A, A_inv, fold, pf, idx->ld, lda);
+    HVS_HIP(hipGetLastError());
 
     SearchParams p;
     memset(&p, 0, sizeof(p));
     p.A = A;
     p.q_inv = A_inv;
     p.nA = nA;
+    p.lda = lda;
     p.X = (const float *)idx->rows;
     p.inv_norm = idx->inv_norm;
     p.groups = idx->groups;
@@ -328,8 +352,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.row_begin = row_begin;
     p.row_end = row_end;
     p.ld = idx->ld;
-    p.nks = (idx->ld + BK - 1) / BK;
-    p.fold = pf;
+    p.nks = (idx->ld + bk - 1) / bk;
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
@@ -339,18 +362,15 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.cap = cap;
     p.QT = (nA + BM - 1) / BM;
     p.T = (row_end - row_begin + BN - 1) / BN;
-    // splits: fill 2 blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
-    int S = (512 + p.QT - 1) / p.QT;
+    // splits: fill the 2 (BK 32) or 3 (BK 16) blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
+    int S = ((bk == 32 ? 512 : 768) + p.QT - 1) / p.QT;
     S = (S + 7) / 8 * 8;
     if ((int64_t)S > p.T) S = (int)p.T;
     if (S >= 8) S = S / 8 * 8;
     if (S < 1) S = 1;
     p.S = S;
-    p.QG = 0;
-    if (const char *e = getenv("HVS_QG")) {
-        const int qg = atoi(e);
-        if (qg > 0 && p.QT % qg == 0 && 8 % (p.QT / qg) == 0 && (S % (8 / (p.QT / qg))) == 0 && (p.QT * S) % 8 == 0) p.QG = qg;
-    }
+    p.dbg = 0;
+    if (const char *e = getenv("HVS_DBG")) p.dbg = atoi(e);
     const int grid = p.QT * S;
     const int groups_per_tile = BM / pf;
 
@@ -367,13 +387,19 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.partial = (uint64_t *)bufA;
     p.overflow = overflow;
 
-    const size_t lds = search_lds_bytes();
+    const size_t lds = search_lds_bytes(bk);
     HVS_TRY(hvs_prof_begin(idx));
 #define HVS_LAUNCH_SEARCH(F)                                                                                         \
     do {                                                                                                             \
-        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F>),                          \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-        mfma_search_kernel<F><<<grid, GT, lds, idx->stream>>>(p);                                                    \
+        if (bk == 32) {                                                                                              \
+            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F, 32>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            mfma_search_kernel<F, 32><<<grid, GT, lds, idx->stream>>>(p);                                            \
+        } else {                                                                                                     \
+            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F, 16>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
+            mfma_search_kernel<F, 16><<<grid, GT, lds, idx->stream>>>(p);                                            \
+        }                                                                                                            \
     } while (0)
     if (pf == 1) HVS_LAUNCH_SEARCH(1);
     else if (pf == 2) HVS_LAUNCH_SEARCH(2);
@@ -385,11 +411,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     int h_overflow = 0;
-    if (pad_ws || true) {
-        HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
-        HVS_HIP(hipStreamSynchronize(idx->stream));
-    }
-    if (pad_ws) HVS_HIP(hipFree(pad_ws));
+    HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
     HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
     return 0;
 }

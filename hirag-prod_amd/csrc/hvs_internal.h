@@ -66,7 +66,7 @@ struct hvs_index {
     int64_t n = 0;
     int64_t cap = 0;
 
-    hvs_workspace ws[4];  // scratch buffers reused across calls: 0 queries, 1/2 candidate lists, 3 staging
+    hvs_workspace ws[6];  // scratch buffers reused across calls: 0 queries, 1/2 candidate lists, 3 staging, 4 MFMA A operand, 5 spare
 
     bool profiling = false;
     double prof_ms[HVS_PROF_COUNT] = {0};

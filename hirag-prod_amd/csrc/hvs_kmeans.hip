@@ -8,7 +8,8 @@
 #include "hvs_gemm_tile.h"
 
 struct AssignParams {
-    const float *C;        // centroids [K, ld] (padded copy)
+    const float *C;        // centroids [K, ldc] (padded copy, ldc a multiple of BK, pad columns zero)
+    int ldc;
     const float *c_norm;   // [K] |c|^2
     int K;
     const float *X;        // corpus
@@ -20,14 +21,17 @@ struct AssignParams {
 };
 
 __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
+    constexpr int BK = 32;
+    constexpr int STAGE = STAGE_FLOATS(BK);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *stages = reinterpret_cast<float *>(smem);
-    float *cn_lds = stages + 2 * STAGE_FLOATS;                                   // [BM]
+    float *cn_lds = stages + 2 * STAGE;                                   // [BM]
     uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + BM);                   // [2][64] keys (wm = 1 -> wm = 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5;
 
@@ -49,12 +53,20 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
 
     f32x16 acc[2][2];
     zero_acc(acc);
-    TileRegs regs;
     const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
-    const int64_t a_last = p.K - 1, b_last = p.n - 1;
+    TileSrc<BK> srcA, srcB;
+    {
+        const int64_t a_valid = p.K - a_row0;
+        tile_src_init(srcA, p.C, a_row0, a_valid < BM ? (int)a_valid : BM, p.ldc, tid);
+    }
+    auto init_b = [&](int64_t tile) {
+        const int64_t r0 = tile * BN;
+        const int64_t valid = p.n - r0;
+        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld, tid);
+    };
     if (total_steps > 0) {
-        load_tiles(regs, p.C, a_row0, a_last, p.X, tile_lo * BN, b_last, p.ld, 0, tid);
-        store_tiles(regs, stages, tid);
+        init_b(tile_lo);
+        dma_tiles<BK>(srcA, srcB, stages, 0, wave);
     }
     __syncthreads();
 
@@ -66,27 +78,33 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
         int64_t ntile = tile;
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
         const bool have_next = g + 1 < total_steps;
-        if (have_next) load_tiles(regs, p.C, a_row0, a_last, p.X, ntile * BN, b_last, p.ld, ks_next * BK, tid);
-
-        compute_step(acc, stages + cur * STAGE_FLOATS, wm, wn, lane);
+        if (have_next && ks_next == 0) init_b(ntile);
+        compute_step<BK>(acc, stages + cur * STAGE, wm, wn, lane, have_next, srcA, srcB, stages + (cur ^ 1) * STAGE,
+                         ks_next * BK, wave);
 
         uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
         const bool last = ks == p.nks - 1;
         if (last) {
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                uint64_t b = HVS_KEY_EMPTY;
+                // per lane: strict "<" over increasing centroid index keeps the lowest index on ties
+                float bv = __builtin_inff();
+                int bi = -1;
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const int a_loc = wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        const float v = fmaf(-2.0f, acc[mt][nt][e], cn_lds[a_loc]);
-                        if (v == v) {
-                            const uint64_t key = hvs_make_key(hvs_ord(v), (uint32_t)(a_row0 + a_loc));
-                            b = key < b ? key : b;
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int a_loc = wm * 64 + mt * 32 + 8 * gq + 4 * h;
+                        const f32x4 cn = *reinterpret_cast<const f32x4 *>(cn_lds + a_loc);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float v = fmaf(-2.0f, acc[mt][nt][4 * gq + e], cn[e]);
+                            const bool lt = v < bv;  // false for NaN
+                            bv = lt ? v : bv;
+                            bi = lt ? a_loc + e : bi;
                         }
                     }
+                uint64_t b = bi >= 0 ? hvs_make_key(hvs_ord(bv), (uint32_t)(a_row0 + bi)) : HVS_KEY_EMPTY;
                 // the other lane half holds the other centroid rows of the same corpus row
                 const uint32_t olo = __shfl_xor((uint32_t)b, 32);
                 const uint32_t ohi = __shfl_xor((uint32_t)(b >> 32), 32);
@@ -100,7 +118,6 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
             }
         }
 
-        if (have_next) store_tiles(regs, stages + (cur ^ 1) * STAGE_FLOATS, tid);
         __syncthreads();
 
         if (last && wm == 0 && h == 0) {
@@ -116,6 +133,7 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
         ks = ks_next;
         tile = ntile;
     }
+#endif
 }
 
 // assign[r] = centroid of the minimum key over the CT tiles; deleted rows -> -1
@@ -135,14 +153,14 @@ __global__ void kmeans_reduce_kernel(const uint64_t *__restrict__ best, int CT, 
 
 // c_pad[j][0..ld) = centroid j zero-padded; c_norm[j] = |c_j|^2.  One wave per centroid.
 __global__ void prep_centroids_kernel(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ c_norm,
-                                      int K, int dim, int ld) {
+                                      int K, int dim, int ldc) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (j >= K) return;
     float s = 0.0f;
-    for (int c = lane; c < ld; c += 64) {
+    for (int c = lane; c < ldc; c += 64) {
         const float v = c < dim ? src[(size_t)j * dim + c] : 0.0f;
-        dst[(size_t)j * ld + c] = v;
+        dst[(size_t)j * ldc + c] = v;
         s = fmaf(v, v, s);
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
     }
 }
 
-static size_t assign_lds_bytes() { return (size_t)2 * STAGE_FLOATS * 4 + BM * 4 + 2 * 64 * 8; }
+static size_t assign_lds_bytes() { return (size_t)2 * STAGE_FLOATS(32) * 4 + BM * 4 + 2 * 64 * 8; }
 
 extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids, int32_t *out_assign,
                                  float *out_sums, int64_t *out_counts, int on_device) {
@@ -182,10 +200,11 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     }
     HVS_HIP(hipSetDevice(idx->device));
     const int K = n_centroids, dim = idx->dim, ld = idx->ld;
+    const int ldc = (ld + 31) / 32 * 32;
     hipStream_t st = idx->stream;
 
     // workspace 0: padded centroids + norms (+ raw host copy); workspace 1: best keys; workspace 3: host staging
-    const size_t cpad_bytes = (size_t)K * ld * 4;
+    const size_t cpad_bytes = (size_t)K * ldc * 4;
     const size_t norm_off = (cpad_bytes + 255) & ~(size_t)255;
     const size_t raw_off = (norm_off + (size_t)K * 4 + 255) & ~(size_t)255;
     const size_t raw_bytes = on_device ? 0 : (size_t)K * dim * 4;
@@ -198,7 +217,7 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     }
     float *c_pad = (float *)ws0;
     float *c_norm = (float *)((char *)ws0 + norm_off);
-    prep_centroids_kernel<<<(K + 3) / 4, 256, 0, st>>>(src, c_pad, c_norm, K, dim, ld);
+    prep_centroids_kernel<<<(K + 3) / 4, 256, 0, st>>>(src, c_pad, c_norm, K, dim, ldc);
     HVS_HIP(hipGetLastError());
 
     AssignParams p;
@@ -209,7 +228,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     p.X = (const float *)idx->rows;
     p.n = n;
     p.ld = ld;
-    p.nks = (ld + BK - 1) / BK;
+    p.ldc = ldc;
+    p.nks = ldc / 32;
     p.CT = (K + BM - 1) / BM;
     p.T = (n + BN - 1) / BN;
     int S = (512 + p.CT - 1) / p.CT;
