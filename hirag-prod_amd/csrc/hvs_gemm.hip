@@ -1,14 +1,14 @@
-// Batched exact search and k-means assignment as an LDS-staged fp32 MFMA contraction (gfx950).
+// Batched exact search as an LDS-staged MFMA contraction (gfx950).
 //
-// S[a, n] = sum_k A[a, k] * X[n, k]      A = query embeddings (search) or centroids (k-means),
-//                                          X = the stored rows; both fp32, row pitch ld.
+// S[a, n] = sum_k A[a, k] * X[n, k]      A = query embeddings, X = the stored rows (fp32, fp16 or bf16;
+//                                          A is held in the same type, accumulation is fp32).
 // Block tile 128 (A rows) x 128 (corpus rows), 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 tiles of
-// v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain).  Corpus rows sit on the MFMA column
+// v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain) or v_mfma_f32_32x32x16_{f16,bf16}.  Corpus rows sit on the MFMA column
 // (= lane) axis, A rows on the accumulator-register axis, so per-corpus-row quantities (inverse norm,
 // filter bit, running argmin) are per-lane scalars and folding consecutive query embeddings (LEAST)
 // is a min over adjacent accumulator registers.
 //
-// The K loop streams 32-float slices of both operands through a double-buffered LDS image filled by
+// The K loop streams 128-byte slices of both operands through a double-buffered LDS image filled by
 // LDS-DMA (buffer_load_dwordx4 ... lds, XOR swizzle applied on the source address so that the
 // ds_read_b128 fragment reads are conflict-free); the DMA of step g+1 is in flight while step g's
 // 64 MFMAs per wave run.
@@ -23,18 +23,18 @@
 // search
 // ---------------------------------------------------------------------------------------------
 struct SearchParams {
-    const float *A;      // prepared queries [nA, lda], lda a multiple of BK, pad columns zero
+    const void *A;       // prepared queries [nA] rows of lda_bytes (a multiple of KB, pad zero), element type = the index's
     const float *q_inv;  // [nA]
     int nA;              // nq_out * FOLD
-    int lda;
-    const float *X;      // corpus [*, ld]
+    int lda_bytes;
+    const void *X;       // corpus rows of ld_bytes
     const float *inv_norm;
     const int32_t *groups;
     const uint32_t *mask;
     const uint32_t *deleted;
     int32_t group_filter;
     int64_t row_begin, row_end;
-    int ld, nks;
+    int ld_bytes, nks;
     int nq_out;  // output queries
     int k;
     float thr;
@@ -99,13 +99,12 @@ __device__ __forceinline__ float prefilter_bound(float tau, float q_inv) {
     return t - fabsf(t) * 4e-7f;
 }
 
-template <int FOLD, int BK>
-__global__ __launch_bounds__(GT, BK == 32 ? 2 : 3) void mfma_search_kernel(SearchParams p) {
+template <int DT, int FOLD>
+__global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
-    constexpr int STAGE = STAGE_FLOATS(BK);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *stages = reinterpret_cast<float *>(smem);                          // 2 * STAGE_FLOATS
-    float *tau_lds = stages + 2 * STAGE;                               // [BM] per folded query
+    char *stages = smem;                                                      // 2 * STAGE_BYTES
+    float *tau_lds = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);       // [BM] per folded query
     int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM] per folded query
     float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM] per A row
     float *bound_lds = qinv_lds + BM;                                         // [BM] per A row
@@ -148,19 +147,19 @@ __global__ __launch_bounds__(GT, BK == 32 ? 2 : 3) void mfma_search_kernel(Searc
     zero_acc(acc);
     const int64_t n_tiles = tile_hi - tile_lo;
     const int64_t total_steps = n_tiles * p.nks;
-    TileSrc<BK> srcA, srcB;
+    TileSrc srcA, srcB;
     {
         const int64_t a_valid = p.nA - a_row0;
-        tile_src_init(srcA, p.A, a_row0, a_valid < BM ? (int)a_valid : BM, p.lda, tid);
+        tile_src_init(srcA, p.A, a_row0, a_valid < BM ? (int)a_valid : BM, p.lda_bytes, tid);
     }
     auto init_b = [&](int64_t tile) {
         const int64_t r0 = p.row_begin + tile * BN;
         const int64_t valid = p.row_end - r0;
-        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld, tid);
+        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld_bytes, tid);
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles<BK>(srcA, srcB, stages, 0, wave);
+        dma_tiles(srcA, srcB, stages, 0, wave);
     }
     __syncthreads();
 
@@ -175,8 +174,8 @@ __global__ __launch_bounds__(GT, BK == 32 ? 2 : 3) void mfma_search_kernel(Searc
         const bool have_next = g + 1 < total_steps;
         const bool prefetch = have_next && !(p.dbg & 1);
         if (prefetch && nks_next == 0) init_b(ntile);
-        compute_step<BK>(acc, stages + cur * STAGE, wm, wn, lane, prefetch, srcA, srcB, stages + (cur ^ 1) * STAGE,
-                         nks_next * BK, wave);
+        compute_step<DT>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, prefetch, srcA, srcB,
+                         stages + (cur ^ 1) * STAGE_BYTES, nks_next, wave);
 
         if (ks == p.nks - 1) {
           if (!(p.dbg & 8)) {
@@ -299,26 +298,50 @@ __global__ __launch_bounds__(GT, BK == 32 ? 2 : 3) void mfma_search_kernel(Searc
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count);
 
-static size_t search_lds_bytes(int bk) { return (size_t)2 * STAGE_FLOATS(bk) * 4 + BM * 16 + (size_t)4 * CAND_MAX * 8; }
+static size_t search_lds_bytes() { return (size_t)2 * STAGE_BYTES + BM * 16 + (size_t)4 * CAND_MAX * 8; }
 
 static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
 
 bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k) {
     (void)nq;
-    return idx->dtype == HVS_F32 && fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_MAX_K;
+    (void)idx;
+    return fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_MAX_K;
 }
 
-// A operand: groups of `pf` rows per output query (the last embedding repeated when fold < pf), row
-// pitch lda (a multiple of BK, pad columns zero), with the matching inverse norms.
-__global__ void build_a_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, float *__restrict__ dst,
+// A operand: groups of `pf` rows per output query (the last embedding repeated when fold < pf), in the
+// index's element type (the prepared queries are already rounded to it, so the conversion is exact),
+// row pitch lda_bytes (a multiple of KB, pad zero), with the matching inverse norms.
+template <typename T> __device__ __forceinline__ T a_cvt(float v);
+template <> __device__ __forceinline__ float a_cvt<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half a_cvt<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ uint16_t a_cvt<uint16_t>(float v) { return hvs_float_to_bf16(v); }
+
+template <typename T>
+__global__ void build_a_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, T *__restrict__ dst,
                                float *__restrict__ dst_inv, int fold, int pf, int ld, int lda) {
     const int row = blockIdx.x;  // destination row
     const int q = row / pf, j = row % pf;
     const int sj = j < fold ? j : fold - 1;
     const float *s = src + ((size_t)q * fold + sj) * ld;
-    float *d = dst + (size_t)row * lda;
-    for (int c = threadIdx.x; c < lda; c += blockDim.x) d[c] = c < ld ? s[c] : 0.0f;
+    T *d = dst + (size_t)row * lda;
+    for (int c = threadIdx.x; c < lda; c += blockDim.x) d[c] = a_cvt<T>(c < ld ? s[c] : 0.0f);
     if (threadIdx.x == 0) dst_inv[row] = src_inv[q * fold + sj];
+}
+
+template <int DT>
+static int launch_search(int pf, int grid, size_t lds, hipStream_t st, const SearchParams &p) {
+#define HVS_LAUNCH_SEARCH(F)                                                                                         \
+    do {                                                                                                             \
+        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<DT, F>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        mfma_search_kernel<DT, F><<<grid, GT, lds, st>>>(p);                                                         \
+    } while (0)
+    if (pf == 1) HVS_LAUNCH_SEARCH(1);
+    else if (pf == 2) HVS_LAUNCH_SEARCH(2);
+    else HVS_LAUNCH_SEARCH(4);
+#undef HVS_LAUNCH_SEARCH
+    HVS_HIP(hipGetLastError());
+    return 0;
 }
 
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
@@ -326,24 +349,29 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
                     int64_t *d_ids, int32_t *d_count) {
     const int pf = padded_fold(fold);
     const int nA = nq * pf;
-    int bk = 32;
-    if (const char *e = getenv("HVS_BK")) bk = atoi(e) == 16 ? 16 : 32;
-    const int lda = (idx->ld + 31) / 32 * 32;
+    const int esz = idx->elem_size;
+    const int ld_bytes = idx->ld * esz;
+    const int lda_bytes = (ld_bytes + KB - 1) / KB * KB;
+    const int lda = lda_bytes / esz;
     void *a_ws = nullptr;
-    const size_t a_bytes = ((size_t)nA * lda * 4 + 255) & ~(size_t)255;
+    const size_t a_bytes = ((size_t)nA * lda_bytes + 255) & ~(size_t)255;
     HVS_TRY(hvs_ws_get(idx, 4, a_bytes + (size_t)nA * 4, &a_ws));
-    float *A = (float *)a_ws;
     float *A_inv = (float *)((char *)a_ws + a_bytes);
-    build_a_kernel<<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, A, A_inv, fold, pf, idx->ld, lda);
+    if (idx->dtype == HVS_F32)
+        build_a_kernel<float><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (float *)a_ws, A_inv, fold, pf, idx->ld, lda);
+    else if (idx->dtype == HVS_F16)
+        build_a_kernel<__half><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (__half *)a_ws, A_inv, fold, pf, idx->ld, lda);
+    else
+        build_a_kernel<uint16_t><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (uint16_t *)a_ws, A_inv, fold, pf, idx->ld, lda);
     HVS_HIP(hipGetLastError());
 
     SearchParams p;
     memset(&p, 0, sizeof(p));
-    p.A = A;
+    p.A = a_ws;
     p.q_inv = A_inv;
     p.nA = nA;
-    p.lda = lda;
-    p.X = (const float *)idx->rows;
+    p.lda_bytes = lda_bytes;
+    p.X = idx->rows;
     p.inv_norm = idx->inv_norm;
     p.groups = idx->groups;
     p.mask = d_mask;
@@ -351,8 +379,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.group_filter = group_filter;
     p.row_begin = row_begin;
     p.row_end = row_end;
-    p.ld = idx->ld;
-    p.nks = (idx->ld + bk - 1) / bk;
+    p.ld_bytes = ld_bytes;
+    p.nks = lda_bytes / KB;
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
@@ -362,8 +390,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.cap = cap;
     p.QT = (nA + BM - 1) / BM;
     p.T = (row_end - row_begin + BN - 1) / BN;
-    // splits: fill the 2 (BK 32) or 3 (BK 16) blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
-    int S = ((bk == 32 ? 512 : 768) + p.QT - 1) / p.QT;
+    // splits: fill the 2 blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
+    int S = (512 + p.QT - 1) / p.QT;
     S = (S + 7) / 8 * 8;
     if ((int64_t)S > p.T) S = (int)p.T;
     if (S >= 8) S = S / 8 * 8;
@@ -387,25 +415,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.partial = (uint64_t *)bufA;
     p.overflow = overflow;
 
-    const size_t lds = search_lds_bytes(bk);
+    const size_t lds = search_lds_bytes();
     HVS_TRY(hvs_prof_begin(idx));
-#define HVS_LAUNCH_SEARCH(F)                                                                                         \
-    do {                                                                                                             \
-        if (bk == 32) {                                                                                              \
-            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F, 32>),                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-            mfma_search_kernel<F, 32><<<grid, GT, lds, idx->stream>>>(p);                                            \
-        } else {                                                                                                     \
-            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<F, 16>),                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                      \
-            mfma_search_kernel<F, 16><<<grid, GT, lds, idx->stream>>>(p);                                            \
-        }                                                                                                            \
-    } while (0)
-    if (pf == 1) HVS_LAUNCH_SEARCH(1);
-    else if (pf == 2) HVS_LAUNCH_SEARCH(2);
-    else HVS_LAUNCH_SEARCH(4);
-#undef HVS_LAUNCH_SEARCH
-    HVS_HIP(hipGetLastError());
+    if (idx->dtype == HVS_F32) HVS_TRY(launch_search<HVS_F32>(pf, grid, lds, idx->stream, p));
+    else if (idx->dtype == HVS_F16) HVS_TRY(launch_search<HVS_F16>(pf, grid, lds, idx->stream, p));
+    else HVS_TRY(launch_search<HVS_BF16>(pf, grid, lds, idx->stream, p));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
     HVS_TRY(hvs_prof_begin(idx));
     HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count));

@@ -22,11 +22,9 @@ struct AssignParams {
 
 __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
-    constexpr int BK = 32;
-    constexpr int STAGE = STAGE_FLOATS(BK);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *stages = reinterpret_cast<float *>(smem);
-    float *cn_lds = stages + 2 * STAGE;                                   // [BM]
+    char *stages = smem;
+    float *cn_lds = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);           // [BM]
     uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + BM);                   // [2][64] keys (wm = 1 -> wm = 0)
 
     const int tid = threadIdx.x;
@@ -54,19 +52,19 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
     f32x16 acc[2][2];
     zero_acc(acc);
     const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
-    TileSrc<BK> srcA, srcB;
+    TileSrc srcA, srcB;
     {
         const int64_t a_valid = p.K - a_row0;
-        tile_src_init(srcA, p.C, a_row0, a_valid < BM ? (int)a_valid : BM, p.ldc, tid);
+        tile_src_init(srcA, p.C, a_row0, a_valid < BM ? (int)a_valid : BM, p.ldc * 4, tid);
     }
     auto init_b = [&](int64_t tile) {
         const int64_t r0 = tile * BN;
         const int64_t valid = p.n - r0;
-        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld, tid);
+        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld * 4, tid);
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles<BK>(srcA, srcB, stages, 0, wave);
+        dma_tiles(srcA, srcB, stages, 0, wave);
     }
     __syncthreads();
 
@@ -79,8 +77,8 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
         const bool have_next = g + 1 < total_steps;
         if (have_next && ks_next == 0) init_b(ntile);
-        compute_step<BK>(acc, stages + cur * STAGE, wm, wn, lane, have_next, srcA, srcB, stages + (cur ^ 1) * STAGE,
-                         ks_next * BK, wave);
+        compute_step<HVS_F32>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, have_next, srcA, srcB,
+                              stages + (cur ^ 1) * STAGE_BYTES, ks_next, wave);
 
         uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
         const bool last = ks == p.nks - 1;
@@ -185,7 +183,7 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
     }
 }
 
-static size_t assign_lds_bytes() { return (size_t)2 * STAGE_FLOATS(32) * 4 + BM * 4 + 2 * 64 * 8; }
+static size_t assign_lds_bytes() { return (size_t)2 * STAGE_BYTES + BM * 4 + 2 * 64 * 8; }
 
 extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids, int32_t *out_assign,
                                  float *out_sums, int64_t *out_counts, int on_device) {

@@ -120,7 +120,9 @@ __device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k
 }
 
 // ---- the scan -----------------------------------------------------------------------------------
-template <int DT, int NQ, bool DISTONLY>
+// LPR = lanes per row: 64 (one row per wave pass) or 32 (two rows per pass, for rows of <= 2 KB, which
+// would otherwise leave half the lanes idle and pay the reduction and selection once per 1.5 KB).
+template <int DT, int NQ, int LPR, bool DISTONLY>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [NQ * ld] floats of queries, then per-wave lists [SCAN_WAVES][nq_out][k] keys, then counts
@@ -129,9 +131,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_floats * 4 + 15) & ~(size_t)15));
     int *cnts = reinterpret_cast<int *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);
 
+    constexpr int SUB = 64 / LPR;     // rows per wave pass
+    constexpr int RG = SCAN_R * SUB;  // rows per wave iteration
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int sub = lane / LPR;
+    const int l = lane % LPR;
     const int nq_total = p.nq_out * p.fold;
 
     for (int i = tid; i < q_floats; i += SCAN_THREADS) {
@@ -152,17 +158,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     for (int q = 0; q < NQ; q++) { tau[q] = thr_key; cnt[q] = 0; }
 
     const u32x4 *rows16 = reinterpret_cast<const u32x4 *>(p.rows);
-    const int64_t n_groups = (p.row_end - p.row_begin + SCAN_R - 1) / SCAN_R;
+    const int64_t n_groups = (p.row_end - p.row_begin + RG - 1) / RG;
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
     constexpr int EPC = Chunk<DT>::N;
 
     for (int64_t g = gwave; g < n_groups; g += nwaves) {
-        const int64_t r0 = p.row_begin + g * SCAN_R;
+        const int64_t r0 = p.row_begin + g * RG + sub;
         bool live[SCAN_R];
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++) {
-            const int64_t row = r0 + r;
+            const int64_t row = r0 + r * SUB;
             bool ok = row < p.row_end;
             if (!DISTONLY && ok) {
                 if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
@@ -178,12 +184,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             for (int q = 0; q < NQ; q++) acc[r][q] = 0.0f;
 
 #pragma unroll 2
-        for (int c = lane; c < p.chunks; c += 64) {
+        for (int c = l; c < p.chunks; c += LPR) {
             u32x4 v[SCAN_R];
 #pragma unroll
             for (int r = 0; r < SCAN_R; r++) {
                 v[r] = (u32x4){0u, 0u, 0u, 0u};
-                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + (r0 + r) * p.chunks + c);
+                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + (r0 + r * SUB) * p.chunks + c);
             }
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -203,43 +209,38 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 }
             }
         }
-        // all-lanes butterfly: every lane ends with the full dot products
+        // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++)
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
                 float s = acc[r][q];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
                 acc[r][q] = s;
             }
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++) {
-            const int64_t row = r0 + r;
-            if (!live[r]) continue;  // wave-uniform
-            const float inv = p.inv_norm[row];
+            const int64_t row = r0 + r * SUB;
+            const float inv = live[r] ? p.inv_norm[row] : 0.0f;
+            float dd[NQ];
+#pragma unroll
+            for (int t = 0; t < NQ; t++) dd[t] = hvs_cos_dist(acc[r][t], inv, qinv[t]);
 #pragma unroll
             for (int qo = 0; qo < NQ; qo++) {
                 if (qo >= p.nq_out) break;
                 float d = __builtin_nanf("");
-                for (int j = 0; j < p.fold; j++) {
-                    const int q = qo * p.fold + j;
-                    float dq = 0.0f, iq = 0.0f;
 #pragma unroll
-                    for (int t = 0; t < NQ; t++) if (t == q) { dq = acc[r][t]; iq = qinv[t]; }
-                    d = fminf(d, hvs_cos_dist(dq, inv, iq));  // fminf drops a NaN operand: LEAST semantics
+                for (int t = 0; t < NQ; t++) {
+                    const int j = t - qo * p.fold;  // wave-uniform
+                    if (j >= 0 && j < p.fold) d = fminf(d, dd[t]);  // fminf drops a NaN operand: LEAST semantics
                 }
                 if (DISTONLY) {
-                    if (lane == 0) p.dist_out[row - p.row_begin] = d;
+                    if (l == 0 && row < p.row_end) p.dist_out[row - p.row_begin] = d;
                 } else {
-                    const uint64_t key = (d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
-                    if (key < tau[qo]) {  // wave-uniform
-                        wave_insert(myL + (size_t)qo * p.k, cnt[qo], p.k, key, lane);
-                        if (cnt[qo] == p.k) {
-                            wave_fence();
-                            tau[qo] = myL[(size_t)qo * p.k + p.k - 1];
-                        }
-                    }
+                    // one lane per row offers the row's key; NaN distances and filtered rows offer nothing
+                    const uint64_t key = (l == 0 && live[r] && d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
+                    wave_offer(myL + (size_t)qo * p.k, cnt[qo], p.k, tau[qo], thr_key, key, lane);
                 }
             }
         }
@@ -378,32 +379,53 @@ int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int 
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------
-template <int DT, bool DISTONLY>
-static int launch_scan_nq(int NQ, int grid, size_t lds, hipStream_t s, const ScanParams &p) {
-#define HVS_SCAN_CASE(N)                                                                                      \
-    case N:                                                                                                   \
-        if (lds > 48 * 1024)                                                                                  \
-            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<DT, N, DISTONLY>),       \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        scan_kernel<DT, N, DISTONLY><<<grid, SCAN_THREADS, lds, s>>>(p);                                     \
-        break;
-    switch (NQ) {
-        HVS_SCAN_CASE(1)
-        HVS_SCAN_CASE(2)
-        HVS_SCAN_CASE(4)
-        HVS_SCAN_CASE(8)
-    default: hvs_set_error("scan: unsupported NQ %d", NQ); return 2;
-    }
-#undef HVS_SCAN_CASE
+// *grid = 0 on entry: size the grid so that every block is resident at once (occupancy x CUs); waves
+// stride over the rows, so a second, partial round of blocks would run at a fraction of the bandwidth.
+template <int DT, int NQ, int LPR, bool DISTONLY>
+static int launch_scan_one(int64_t want_blocks, size_t lds, hipStream_t s, const ScanParams &p, int *grid_out, bool dry) {
+    const void *fn = reinterpret_cast<const void *>(&scan_kernel<DT, NQ, LPR, DISTONLY>);
+    if (lds > 48 * 1024) HVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SCAN_THREADS, lds));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    int dev = 0, cus = 256;
+    HVS_HIP(hipGetDevice(&dev));
+    HVS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int64_t grid = (int64_t)per_cu * cus;
+    if (want_blocks < grid) grid = want_blocks < 1 ? 1 : want_blocks;
+    *grid_out = (int)grid;
+    if (dry) return 0;
+    scan_kernel<DT, NQ, LPR, DISTONLY><<<(int)grid, SCAN_THREADS, lds, s>>>(p);
     HVS_HIP(hipGetLastError());
     return 0;
 }
 
+template <int DT, int LPR, bool DISTONLY>
+static int launch_scan_nq(int NQ, int64_t want, size_t lds, hipStream_t s, const ScanParams &p, int *grid, bool dry) {
+    switch (NQ) {
+    case 1: return launch_scan_one<DT, 1, LPR, DISTONLY>(want, lds, s, p, grid, dry);
+    case 2: return launch_scan_one<DT, 2, LPR, DISTONLY>(want, lds, s, p, grid, dry);
+    case 4: return launch_scan_one<DT, 4, LPR, DISTONLY>(want, lds, s, p, grid, dry);
+    case 8: return launch_scan_one<DT, 8, LPR, DISTONLY>(want, lds, s, p, grid, dry);
+    default: hvs_set_error("scan: unsupported NQ %d", NQ); return 2;
+    }
+}
+
+// lanes per row: two rows per wave pass when a row is at most 2 KB
+static inline int scan_lpr(int chunks) { return chunks <= 128 ? 32 : 64; }
+
 template <bool DISTONLY>
-static int launch_scan(int dtype, int NQ, int grid, size_t lds, hipStream_t s, const ScanParams &p) {
-    if (dtype == HVS_F32) return launch_scan_nq<HVS_F32, DISTONLY>(NQ, grid, lds, s, p);
-    if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, DISTONLY>(NQ, grid, lds, s, p);
-    return launch_scan_nq<HVS_BF16, DISTONLY>(NQ, grid, lds, s, p);
+static int launch_scan(int dtype, int NQ, int lpr, int64_t want, size_t lds, hipStream_t s, const ScanParams &p, int *grid,
+                       bool dry) {
+    if (DISTONLY || lpr == 64) {
+        if (dtype == HVS_F32) return launch_scan_nq<HVS_F32, 64, DISTONLY>(NQ, want, lds, s, p, grid, dry);
+        if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, 64, DISTONLY>(NQ, want, lds, s, p, grid, dry);
+        return launch_scan_nq<HVS_BF16, 64, DISTONLY>(NQ, want, lds, s, p, grid, dry);
+    }
+    if (dtype == HVS_F32) return launch_scan_nq<HVS_F32, 32, false>(NQ, want, lds, s, p, grid, dry);
+    if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, 32, false>(NQ, want, lds, s, p, grid, dry);
+    return launch_scan_nq<HVS_BF16, 32, false>(NQ, want, lds, s, p, grid, dry);
 }
 
 static inline int round_nq(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
@@ -430,11 +452,18 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const size_t lds = scan_lds_bytes(NQ, idx->ld, per_pass, k);
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_search: dim %d with fold %d and k %d needs %zu bytes of LDS (limit %zu)", idx->dim, fold, k, lds, LDS_LIMIT);
 
+    const int chunks = idx->ld * idx->elem_size / 16;
+    const int lpr = scan_lpr(chunks);
     const int64_t n_rows = row_end - row_begin;
-    const int64_t row_groups = (n_rows + SCAN_R - 1) / SCAN_R;
-    int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
-    int grid = 256 * 4;
-    if (want_blocks < grid) grid = (int)(want_blocks < 1 ? 1 : want_blocks);
+    const int rows_per_iter = SCAN_R * (64 / lpr);
+    const int64_t row_groups = (n_rows + rows_per_iter - 1) / rows_per_iter;
+    const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
+    int grid = 0;
+    {
+        ScanParams dummy;
+        memset(&dummy, 0, sizeof(dummy));
+        HVS_TRY(launch_scan<false>(idx->dtype, NQ, lpr, want_blocks, lds, idx->stream, dummy, &grid, true));
+    }
     const int P = grid;
     const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
     void *bufA = nullptr, *bufB = nullptr;
@@ -450,7 +479,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.row_begin = row_begin;
     p.row_end = row_end;
     p.ld = idx->ld;
-    p.chunks = idx->ld * idx->elem_size / 16;
+    p.chunks = chunks;
     p.fold = fold;
     p.k = k;
     p.thr_ord = 0;
@@ -469,9 +498,10 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         p.queries = d_q + (size_t)q0 * fold * idx->ld;
         p.q_inv = d_qinv + (size_t)q0 * fold;
         p.nq_out = nqo;
-        const size_t lds_pass = scan_lds_bytes(NQ, idx->ld, nqo, k);
         HVS_TRY(hvs_prof_begin(idx));
-        HVS_TRY(launch_scan<false>(idx->dtype, NQ, grid, lds_pass, idx->stream, p));
+        int g2 = 0;
+        HVS_TRY(launch_scan<false>(idx->dtype, NQ, lpr, grid, lds, idx->stream, p, &g2, false));
+        HVS_REQUIRE(g2 == grid, "scan: grid changed between sizing and launch");
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
         HVS_TRY(hvs_prof_begin(idx));
         HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nqo, P, k, d_dist + (size_t)q0 * k,
@@ -590,11 +620,10 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
     p.group_filter = -1;
     p.dist_out = d_out;
     const int64_t row_groups = (n_rows + SCAN_R - 1) / SCAN_R;
-    int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
-    int grid = 256 * 4;
-    if (want_blocks < grid) grid = (int)want_blocks;
+    const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
+    int grid = 0;
     HVS_TRY(hvs_prof_begin(idx));
-    HVS_TRY(launch_scan<true>(idx->dtype, NQ, grid, lds, idx->stream, p));
+    HVS_TRY(launch_scan<true>(idx->dtype, NQ, 64, want_blocks, lds, idx->stream, p, &grid, false));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
     if (!on_device) {
         HVS_HIP(hipMemcpyAsync(out, d_out, (size_t)n_rows * 4, hipMemcpyDeviceToHost, idx->stream));

@@ -20,27 +20,28 @@ def hvs():
     return hirag_prod_amd
 
 
-def _check_all(rows, q, fold, k, dist, ids, cnt, thr=None, keep=None, label=""):
+def _check_all(rows, q, fold, k, dist, ids, cnt, thr=None, keep=None, label="", storage="f32"):
     nq = q.shape[0] // fold
     rows64 = rows.astype(np.float64)
     for i in range(nq):
-        full = parity.full_distances(rows64, q[i * fold : (i + 1) * fold], "f32")
+        full = parity.full_distances(rows64, q[i * fold : (i + 1) * fold], storage)
         parity.check_topk(dist[i], ids[i], cnt[i], full, k, threshold=thr, keep=keep, label=f"{label} q={i}")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("n,d", [(1000, 96), (20000, 256), (5000, 1536), (130, 40)])
-def test_mfma_search_matches_oracle(hvs, n, d):
+def test_mfma_search_matches_oracle(hvs, n, d, dtype):
     rng = np.random.default_rng(n * 7 + d)
     rows = rng.standard_normal((n, d)).astype(np.float32)
     rows[3] = 0.0
     rows[8] = rows[2]
-    idx = hvs.HvsIndex(d, "f32")
+    idx = hvs.HvsIndex(d, dtype)
     idx.add(rows)
     for nq, k in ((1, 10), (37, 1), (160, 10), (64, 100), (300, 128)):
         q = rng.standard_normal((nq, d)).astype(np.float32)
         q[0] = rows[2]  # an exact hit with an exact tie (rows 2 and 8)
         dist, ids, cnt = idx.search(q, k=k, algo="mfma")
-        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"mfma n={n} d={d} nq={nq} k={k}")
+        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"mfma {dtype} n={n} d={d} nq={nq} k={k}", storage=dtype)
         # the two independent kernels agree with each other as well
         d2, i2, c2 = idx.search(q[:8], k=k, algo="scan")
         np.testing.assert_array_equal(c2, cnt[:8])
@@ -48,13 +49,13 @@ def test_mfma_search_matches_oracle(hvs, n, d):
     idx.close()
 
 
-@pytest.mark.parametrize("fold", [2, 3, 4])
-def test_mfma_fold_threshold_filters(hvs, fold):
+@pytest.mark.parametrize("fold,dtype", [(2, "f32"), (3, "f32"), (4, "f32"), (3, "f16"), (2, "bf16")])
+def test_mfma_fold_threshold_filters(hvs, fold, dtype):
     rng = np.random.default_rng(fold)
     n, d = 9000, 128
     rows = rng.standard_normal((n, d)).astype(np.float32)
     groups = (np.arange(n) % 3).astype(np.int32)
-    idx = hvs.HvsIndex(d, "f32")
+    idx = hvs.HvsIndex(d, dtype)
     idx.add(rows, group_codes=groups)
     nq = 40
     q = rng.standard_normal((nq * fold, d)).astype(np.float32)
@@ -71,14 +72,14 @@ def test_mfma_fold_threshold_filters(hvs, fold):
         if use_mask:
             keep &= keep_bits
         _check_all(rows, q, fold, 10, dist, ids, cnt, thr=None if math.isinf(thr) else thr, keep=keep,
-                   label=f"fold={fold} gf={gf} mask={use_mask} thr={thr}")
+                   label=f"fold={fold} gf={gf} mask={use_mask} thr={thr}", storage=dtype)
     # deleted rows and row ranges
     idx.set_deleted(np.arange(0, n, 2), True)
     dist, ids, cnt = idx.search(q, k=5, fold=fold, row_begin=1001, row_end=7777, algo="mfma")
     keep = np.zeros(n, bool)
     keep[1001:7777] = True
     keep[::2] = False
-    _check_all(rows, q, fold, 5, dist, ids, cnt, keep=keep, label=f"fold={fold} deleted+range")
+    _check_all(rows, q, fold, 5, dist, ids, cnt, keep=keep, label=f"fold={fold} deleted+range", storage=dtype)
     idx.close()
 
 

@@ -21,10 +21,12 @@ if __name__ == "__main__":
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--kmeans", type=int, default=0, help="number of centroids (0 = skip)")
+    ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
     import torch
 
-    idx = hvs.HvsIndex(a.dim, "f32")
+    idx = hvs.HvsIndex(a.dim, a.dtype)
+    peak = 157.3 if a.dtype == "f32" else 2500.0
     idx.fill_synthetic(a.rows, seed=1234)
     q = torch.randn((a.nq, a.dim), device="cuda", generator=torch.Generator("cuda").manual_seed(4321))
     idx.search(q, k=a.k, algo="mfma")
@@ -36,8 +38,8 @@ if __name__ == "__main__":
     mm, nm = idx.profile_get(_lib.HVS_PROF_MERGE)
     per = ms / n
     flops = 2.0 * a.nq * a.rows * a.dim
-    print(f"mfma search rows={a.rows} nq={a.nq} k={a.k}: {per:.2f} ms/batch  {flops / per / 1e9:.1f} TFLOP/s "
-          f"({flops / per / 1e9 / 157.3 * 100:.1f}% of 157.3)  merge {mm / nm:.3f} ms  -> {a.nq / (per + mm / nm) * 1e3:.0f} QPS", flush=True)
+    print(f"mfma search {a.dtype} rows={a.rows} dim={a.dim} nq={a.nq} k={a.k}: {per:.2f} ms/batch  {flops / per / 1e9:.1f} TFLOP/s "
+          f"({flops / per / 1e9 / peak * 100:.1f}% of {peak})  merge {mm / nm:.3f} ms  -> {a.nq / (per + mm / nm) * 1e3:.0f} QPS", flush=True)
     if a.kmeans:
         c = torch.randn((a.kmeans, a.dim), device="cuda")
         idx.profile_reset()
