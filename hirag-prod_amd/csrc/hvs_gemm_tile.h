@@ -91,11 +91,11 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[2][2], const char *st
     const char *Bs = stage + BM * KB;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        f32x4 a[2], b[2];
+        struct { f32x4 a[2], b[2]; } f;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            a[t] = *reinterpret_cast<const f32x4 *>(As + lds_off(wm * 64 + t * 32 + r, 2 * s + h));
-            b[t] = *reinterpret_cast<const f32x4 *>(Bs + lds_off(wn * 64 + t * 32 + r, 2 * s + h));
+            f.a[t] = *reinterpret_cast<const f32x4 *>(As + lds_off(wm * 64 + t * 32 + r, 2 * s + h));
+            f.b[t] = *reinterpret_cast<const f32x4 *>(Bs + lds_off(wn * 64 + t * 32 + r, 2 * s + h));
         }
         if (DT == HVS_F32) {
 #pragma unroll
@@ -104,7 +104,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[2][2], const char *st
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                     for (int nt = 0; nt < 2; nt++)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mt][j], f.b[nt][j], acc[mt][nt], 0, 0, 0);
                 if ((j & 1) == 0) {  // 8 pieces over 16 groups of 4 MFMAs
                     if (prefetch) dma_piece(sa, sb, next_stage, next_step, wave, s * 2 + (j >> 1));
                     __builtin_amdgcn_sched_barrier(0);  // pin the piece between these MFMA groups
@@ -116,11 +116,11 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[2][2], const char *st
 #pragma unroll
                 for (int nt = 0; nt < 2; nt++) {
                     if (DT == HVS_F16)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[mt]),
-                                                                             __builtin_bit_cast(f16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[mt]),
+                                                                             __builtin_bit_cast(f16x8, f.b[nt]), acc[mt][nt], 0, 0, 0);
                     else
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt]),
-                                                                              __builtin_bit_cast(bf16x8, b[nt]), acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[mt]),
+                                                                              __builtin_bit_cast(bf16x8, f.b[nt]), acc[mt][nt], 0, 0, 0);
                     if (nt == 1) {  // 8 pieces over 8 pairs of MFMAs
                         if (prefetch) dma_piece(sa, sb, next_stage, next_step, wave, s * 2 + mt);
                         __builtin_amdgcn_sched_barrier(0);
