@@ -30,42 +30,56 @@ struct ScanParams {
     int k;
     uint32_t thr_ord;  // ordered-uint image of the strict distance bound
     int32_t group_filter;
-    uint64_t *partial;  // [nq_out, gridDim.x, k] keys (topk mode)
+    uint64_t *partial;  // [nq_out, gridDim.x * SCAN_WAVES, k] keys (topk mode)
     float *dist_out;    // [row_end - row_begin] (distance mode)
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- 16-byte chunk -> floats ------------------------------------------------------------------
+// ---- 16 bytes of a row against 16 bytes of a query (same element type, same k range) ----------
+// fp32: four fmaf.  fp16 / bf16: four v_dot2c_f32_{f16,bf16}: two exact products added to the fp32
+// accumulator each; the query is held in the row's own 16-bit type, which loses nothing because it
+// has already been rounded to that type.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
 template <int DT> struct Chunk;
 template <> struct Chunk<HVS_F32> {
-    static constexpr int N = 4;
-    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
-        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    static constexpr int ESZ = 4;
+    __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
+        acc = fmaf(__uint_as_float(v.x), __uint_as_float(q.x), acc);
+        acc = fmaf(__uint_as_float(v.y), __uint_as_float(q.y), acc);
+        acc = fmaf(__uint_as_float(v.z), __uint_as_float(q.z), acc);
+        return fmaf(__uint_as_float(v.w), __uint_as_float(q.w), acc);
     }
+    __device__ static __forceinline__ void put_query(char *dst, int c, float v) { reinterpret_cast<float *>(dst)[c] = v; }
 };
 template <> struct Chunk<HVS_F16> {
-    static constexpr int N = 8;
-    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    static constexpr int ESZ = 2;
+    __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
+        h16x2 a[4], b[4];
+        __builtin_memcpy(a, &v, 16);
+        __builtin_memcpy(b, &q, 16);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const __half2 h = *reinterpret_cast<const __half2 *>(&w[i]);
-            const float2 p = __half22float2(h);
-            f[2 * i] = p.x;
-            f[2 * i + 1] = p.y;
-        }
+        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_fdot2(a[i], b[i], acc, false);
+        return acc;
+    }
+    __device__ static __forceinline__ void put_query(char *dst, int c, float v) {
+        reinterpret_cast<__half *>(dst)[c] = __float2half_rn(v);
     }
 };
 template <> struct Chunk<HVS_BF16> {
-    static constexpr int N = 8;
-    __device__ static __forceinline__ void widen(const u32x4 &v, float (&f)[8]) {
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    static constexpr int ESZ = 2;
+    __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
+        bf16x2 a[4], b[4];
+        __builtin_memcpy(a, &v, 16);
+        __builtin_memcpy(b, &q, 16);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f[2 * i] = __uint_as_float(w[i] << 16);
-            f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
-        }
+        for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_fdot2_f32_bf16(a[i], b[i], acc, false);
+        return acc;
+    }
+    __device__ static __forceinline__ void put_query(char *dst, int c, float v) {
+        reinterpret_cast<uint16_t *>(dst)[c] = hvs_float_to_bf16(v);
     }
 };
 
@@ -125,11 +139,11 @@ __device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k
 template <int DT, int NQ, int LPR, bool DISTONLY>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: [NQ * ld] floats of queries, then per-wave lists [SCAN_WAVES][nq_out][k] keys, then counts
-    float *q_lds = reinterpret_cast<float *>(smem);
-    const int q_floats = NQ * p.ld;
-    uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_floats * 4 + 15) & ~(size_t)15));
-    int *cnts = reinterpret_cast<int *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);
+    // LDS: [NQ][ld] query elements in the row's element type, then per-wave lists [SCAN_WAVES][nq_out][k] keys
+    constexpr int ESZ = Chunk<DT>::ESZ;
+    char *q_lds = smem;
+    const int q_bytes = NQ * p.ld * ESZ;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_bytes + 15) & ~(size_t)15));
 
     constexpr int SUB = 64 / LPR;     // rows per wave pass
     constexpr int RG = SCAN_R * SUB;  // rows per wave iteration
@@ -140,9 +154,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int l = lane % LPR;
     const int nq_total = p.nq_out * p.fold;
 
-    for (int i = tid; i < q_floats; i += SCAN_THREADS) {
+    for (int i = tid; i < NQ * p.ld; i += SCAN_THREADS) {
         const int q = i / p.ld;
-        q_lds[i] = q < nq_total ? p.queries[i] : 0.0f;
+        Chunk<DT>::put_query(q_lds, i, q < nq_total ? p.queries[i] : 0.0f);
     }
     __syncthreads();
 
@@ -161,22 +175,44 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int64_t n_groups = (p.row_end - p.row_begin + RG - 1) / RG;
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
-    constexpr int EPC = Chunk<DT>::N;
 
-    for (int64_t g = gwave; g < n_groups; g += nwaves) {
+    // This wave owns row groups gwave, gwave + nwaves, ...  With a filter (group code, row mask,
+    // tombstones) the wave first evaluates the filter of 64 of its groups at once, one group per lane,
+    // so that the dependent loads of the filter columns cost one round trip per 64 groups instead of
+    // one per group, and then visits only the groups that have a live row.
+    const bool filtered = !DISTONLY && (p.group_filter >= 0 || p.mask != nullptr || p.deleted != nullptr);
+    const int64_t my_groups = n_groups > gwave ? (n_groups - gwave + nwaves - 1) / nwaves : 0;
+    for (int64_t base = 0; base < my_groups; base += 64) {
+        uint32_t mybits = 0;
+        uint64_t todo;
+        if (filtered) {
+            const int64_t gi = base + lane;
+            if (gi < my_groups) {
+                const int64_t row0 = p.row_begin + (gwave + gi * nwaves) * RG;
+#pragma unroll
+                for (int i = 0; i < RG; i++) {
+                    const int64_t row = row0 + i;
+                    bool ok = row < p.row_end;
+                    if (ok && p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+                    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+                    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+                    mybits |= (ok ? 1u : 0u) << i;
+                }
+            }
+            todo = __ballot(mybits != 0);
+        } else {
+            const int64_t left = my_groups - base;
+            todo = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+        }
+      while (todo) {
+        const int j = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int64_t g = gwave + (base + j) * nwaves;
+        const uint32_t bits = filtered ? (uint32_t)__builtin_amdgcn_readlane((int)mybits, j) : 0xFFFFFFFFu;
         const int64_t r0 = p.row_begin + g * RG + sub;
         bool live[SCAN_R];
 #pragma unroll
-        for (int r = 0; r < SCAN_R; r++) {
-            const int64_t row = r0 + r * SUB;
-            bool ok = row < p.row_end;
-            if (!DISTONLY && ok) {
-                if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
-                if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
-                if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
-            }
-            live[r] = ok;
-        }
+        for (int r = 0; r < SCAN_R; r++) live[r] = ((bits >> (r * SUB + sub)) & 1u) && (r0 + r * SUB) < p.row_end;
         float acc[SCAN_R][NQ];
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++)
@@ -193,20 +229,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             }
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                float qf[8];
-                const float4 qa = *reinterpret_cast<const float4 *>(q_lds + q * p.ld + c * EPC);
-                qf[0] = qa.x; qf[1] = qa.y; qf[2] = qa.z; qf[3] = qa.w;
-                if (EPC == 8) {
-                    const float4 qb = *reinterpret_cast<const float4 *>(q_lds + q * p.ld + c * EPC + 4);
-                    qf[4] = qb.x; qf[5] = qb.y; qf[6] = qb.z; qf[7] = qb.w;
-                }
+                const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
 #pragma unroll
-                for (int r = 0; r < SCAN_R; r++) {
-                    float f[8];
-                    Chunk<DT>::widen(v[r], f);
-#pragma unroll
-                    for (int e = 0; e < EPC; e++) acc[r][q] = fmaf(f[e], qf[e], acc[r][q]);
-                }
+                for (int r = 0; r < SCAN_R; r++) acc[r][q] = Chunk<DT>::dot(v[r], qv, acc[r][q]);
             }
         }
         // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
@@ -244,45 +269,82 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 }
             }
         }
+      }
     }
     if (DISTONLY) return;
 
-    // fold the block's wave lists into wave 0's, then publish k keys per query
+    // publish: every wave writes its k keys per query (ascending, padded); the merge kernels do the rest
+    const int64_t n_lists = (int64_t)gridDim.x * SCAN_WAVES;
 #pragma unroll
-    for (int qo = 0; qo < NQ; qo++)
-        if (qo < p.nq_out && lane == 0) cnts[wave * NQ + qo] = cnt[qo];
-    __syncthreads();
-    if (wave != 0) return;
-    for (int qo = 0; qo < p.nq_out; qo++) {
-        int c0 = 0;
-        uint64_t t0 = thr_key;
-#pragma unroll
-        for (int t = 0; t < NQ; t++) if (t == qo) { c0 = cnt[t]; t0 = tau[t]; }
-        volatile uint64_t *L0 = myL + (size_t)qo * p.k;
-        for (int w = 1; w < SCAN_WAVES; w++) {
-            const volatile uint64_t *Lw = lists + ((size_t)w * p.nq_out + qo) * p.k;
-            const int cw = cnts[w * NQ + qo];
-            for (int base = 0; base < cw; base += 64) {
-                const int i = base + lane;
-                const uint64_t key = i < cw ? Lw[i] : HVS_KEY_EMPTY;
-                wave_offer(L0, c0, p.k, t0, thr_key, key, lane);
-            }
-        }
+    for (int qo = 0; qo < NQ; qo++) {
+        if (qo >= p.nq_out) break;
         wave_fence();
-        uint64_t *out = p.partial + ((size_t)qo * gridDim.x + blockIdx.x) * p.k;
-        for (int i = lane; i < p.k; i += 64) out[i] = i < c0 ? L0[i] : HVS_KEY_EMPTY;
+        const volatile uint64_t *L = myL + (size_t)qo * p.k;
+        uint64_t *out = p.partial + ((size_t)qo * n_lists + gwave) * p.k;
+        for (int i = lane; i < p.k; i += 64) out[i] = i < cnt[qo] ? L[i] : HVS_KEY_EMPTY;
     }
 }
 
 // ---- list merging -------------------------------------------------------------------------------
+// A wave holds one ascending list of N = 64 * KL keys in registers, slot i = e * 64 + lane in a[e].
+// Merging another ascending list B keeps the N smallest of the union: c[i] = min(a[i], B[N-1-i]) is a
+// bitonic sequence holding exactly those keys, and log2(N) compare-exchange rounds sort it (rounds with
+// stride >= 64 pair registers of one lane, rounds with stride < 64 pair lanes through a shuffle).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int KL>
+__device__ __forceinline__ void wl_load(uint64_t (&a)[KL], const uint64_t *src, int n, int lane) {
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        a[e] = i < n ? src[i] : HVS_KEY_EMPTY;
+    }
+}
+
+template <int KL>
+__device__ __forceinline__ void wl_merge(uint64_t (&a)[KL], const uint64_t *other, int n, int lane) {
+    constexpr int N = 64 * KL;
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = N - 1 - (e * 64 + lane);  // the other list, reversed
+        const uint64_t b = i < n ? other[i] : HVS_KEY_EMPTY;
+        a[e] = b < a[e] ? b : a[e];
+    }
+#pragma unroll
+    for (int se = KL / 2; se >= 1; se >>= 1) {  // strides 64 * se: register pairs inside a lane
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            if ((e & se) == 0) {
+                const uint64_t lo = a[e] < a[e + se] ? a[e] : a[e + se];
+                const uint64_t hi = a[e] < a[e + se] ? a[e + se] : a[e];
+                a[e] = lo;
+                a[e + se] = hi;
+            }
+        }
+    }
+#pragma unroll
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        const bool keep_min = (lane & stride) == 0;
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const uint64_t o = shfl_xor_u64(a[e], stride);
+            const uint64_t lo = a[e] < o ? a[e] : o;
+            const uint64_t hi = a[e] < o ? o : a[e];
+            a[e] = keep_min ? lo : hi;
+        }
+    }
+}
+
 // in: [nq, P, k] ascending keys padded with HVS_KEY_EMPTY.  One wave merges MERGE_FAN consecutive lists.
 // FINAL = false: out keys [nq, P2, k].  FINAL = true (P2 == 1): distances / ids / counts.
-template <bool FINAL>
+template <int KL, bool FINAL>
 __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restrict__ in, int P, int k, uint64_t *out_keys,
                                                           const int64_t *__restrict__ ids, float *out_dist,
                                                           int64_t *out_ids, int32_t *out_count) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    volatile uint64_t *L = reinterpret_cast<volatile uint64_t *>(smem);
     const int lane = threadIdx.x;
     const int grp = blockIdx.x;
     const int q = blockIdx.y;
@@ -290,50 +352,63 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restr
     const int first = grp * MERGE_FAN;
     const int nl = (P - first) < MERGE_FAN ? (P - first) : MERGE_FAN;
     const uint64_t *src = in + ((size_t)q * P + first) * k;
-    const int64_t total = (int64_t)nl * k;
-    int cnt = 0;
-    uint64_t tau = HVS_KEY_EMPTY;
-    for (int64_t base = 0; base < total; base += 64) {
-        const int64_t i = base + lane;
-        const uint64_t key = i < total ? src[i] : HVS_KEY_EMPTY;
-        wave_offer(L, cnt, k, tau, 0, key, lane);
-    }
-    wave_fence();
+    uint64_t a[KL];
+    wl_load<KL>(a, src, k, lane);
+    for (int j = 1; j < nl; j++) wl_merge<KL>(a, src + (size_t)j * k, k, lane);
     if (!FINAL) {
         uint64_t *o = out_keys + ((size_t)q * P2 + grp) * k;
-        for (int i = lane; i < k; i += 64) o[i] = i < cnt ? L[i] : HVS_KEY_EMPTY;
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const int i = e * 64 + lane;
+            if (i < k) o[i] = a[e];
+        }
     } else {
-        for (int i = lane; i < k; i += 64) {
-            float d = __builtin_inff();
-            int64_t id = -1;
-            if (i < cnt) {
-                const uint64_t key = L[i];
-                d = hvs_unord((uint32_t)(key >> 32));
-                const uint32_t row = (uint32_t)key;
-                id = ids ? ids[row] : (int64_t)row;
+        int cnt = 0;
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const int i = e * 64 + lane;
+            const bool have = i < k && a[e] != HVS_KEY_EMPTY;
+            cnt += __popcll(__ballot(have));
+            if (i < k) {
+                float d = __builtin_inff();
+                int64_t id = -1;
+                if (have) {
+                    d = hvs_unord((uint32_t)(a[e] >> 32));
+                    const uint32_t row = (uint32_t)a[e];
+                    id = ids ? ids[row] : (int64_t)row;
+                }
+                out_dist[(size_t)q * k + i] = d;
+                out_ids[(size_t)q * k + i] = id;
             }
-            out_dist[(size_t)q * k + i] = d;
-            out_ids[(size_t)q * k + i] = id;
         }
         if (lane == 0) out_count[q] = cnt;
     }
 }
 
-// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys
-int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
-                     int64_t *d_ids, int32_t *d_count) {
-    const size_t lds = (size_t)k * 8;
+template <int KL>
+static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
+                           int64_t *d_ids, int32_t *d_count) {
     uint64_t *in = bufA, *out = bufB;
     while (P > MERGE_FAN) {
         const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
-        merge_lists_kernel<false><<<dim3(P2, nq), 64, lds, idx->stream>>>(in, P, k, out, nullptr, nullptr, nullptr, nullptr);
+        merge_lists_kernel<KL, false><<<dim3(P2, nq), 64, 0, idx->stream>>>(in, P, k, out, nullptr, nullptr, nullptr, nullptr);
         HVS_HIP(hipGetLastError());
         uint64_t *t = in; in = out; out = t;
         P = P2;
     }
-    merge_lists_kernel<true><<<dim3(1, nq), 64, lds, idx->stream>>>(in, P, k, nullptr, idx->ids, d_dist, d_ids, d_count);
+    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, idx->ids, d_dist, d_ids, d_count);
     HVS_HIP(hipGetLastError());
     return 0;
+}
+
+// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys
+int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
+                     int64_t *d_ids, int32_t *d_count) {
+    if (k <= 64) return reduce_lists_kl<1>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
+    if (k <= 128) return reduce_lists_kl<2>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
+    if (k <= 256) return reduce_lists_kl<4>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
+    if (k <= 512) return reduce_lists_kl<8>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
+    return reduce_lists_kl<16>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
 }
 
 // ---- query preparation --------------------------------------------------------------------------
@@ -430,8 +505,8 @@ static int launch_scan(int dtype, int NQ, int lpr, int64_t want, size_t lds, hip
 
 static inline int round_nq(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
 
-static size_t scan_lds_bytes(int NQ, int ld, int nq_out, int k) {
-    size_t b = ((size_t)NQ * ld * 4 + 15) & ~(size_t)15;
+static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k) {
+    size_t b = ((size_t)NQ * ld * esz + 15) & ~(size_t)15;
     b += (size_t)SCAN_WAVES * nq_out * k * 8;
     b += (size_t)SCAN_WAVES * NQ * 4;
     return b;
@@ -447,9 +522,9 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     int per_pass = 8 / fold;
     if (per_pass < 1) per_pass = 1;
     if (per_pass > nq) per_pass = nq;
-    while (per_pass > 1 && scan_lds_bytes(round_nq(per_pass * fold), idx->ld, per_pass, k) > LDS_LIMIT / 2) per_pass--;
+    while (per_pass > 1 && scan_lds_bytes(round_nq(per_pass * fold), idx->ld, idx->elem_size, per_pass, k) > LDS_LIMIT / 2) per_pass--;
     const int NQ = round_nq(per_pass * fold);
-    const size_t lds = scan_lds_bytes(NQ, idx->ld, per_pass, k);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, per_pass, k);
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_search: dim %d with fold %d and k %d needs %zu bytes of LDS (limit %zu)", idx->dim, fold, k, lds, LDS_LIMIT);
 
     const int chunks = idx->ld * idx->elem_size / 16;
@@ -464,7 +539,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         memset(&dummy, 0, sizeof(dummy));
         HVS_TRY(launch_scan<false>(idx->dtype, NQ, lpr, want_blocks, lds, idx->stream, dummy, &grid, true));
     }
-    const int P = grid;
+    const int P = grid * SCAN_WAVES;  // one list per wave
     const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
     void *bufA = nullptr, *bufB = nullptr;
     HVS_TRY(hvs_ws_get(idx, 1, (size_t)per_pass * P * k * 8, &bufA));
@@ -602,7 +677,7 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
         d_out = (float *)stage;
     }
     const int NQ = round_nq(fold);
-    const size_t lds = scan_lds_bytes(NQ, idx->ld, 1, 1);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, 1, 1);
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_distances: dim %d with fold %d needs %zu bytes of LDS", idx->dim, fold, lds);
     ScanParams p;
     memset(&p, 0, sizeof(p));

@@ -24,6 +24,19 @@ def full_distances(rows, q_embs, storage):
     return po.least_fold(d)
 
 
+def distance_matrix(rows, q_embs, storage):
+    """float64 cosine distance of every row to every query embedding: ``[nq, n]`` (NaN for zero norms)."""
+    rows_s = po.round_storage(rows, storage)
+    q_s = po.round_storage(np.atleast_2d(q_embs), storage)
+    dot = q_s @ rows_s.T
+    na = np.einsum("ij,ij->i", rows_s, rows_s)
+    nb = np.einsum("ij,ij->i", q_s, q_s)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sim = dot / np.sqrt(nb[:, None] * na[None, :])
+    sim = np.where(sim > 1.0, 1.0, np.where(sim < -1.0, -1.0, sim))
+    return 1.0 - sim
+
+
 def check_topk(gpu_dist, gpu_ids, gpu_cnt, full, k, threshold=None, keep=None, id_of_row=None, label=""):
     """``full``: float64 distance of every row (NaN allowed).  gpu_*: one query's outputs."""
     exp_idx, exp_dist = po.order_by_limit(full, keep, threshold, k)

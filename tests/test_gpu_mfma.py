@@ -22,9 +22,9 @@ def hvs():
 
 def _check_all(rows, q, fold, k, dist, ids, cnt, thr=None, keep=None, label="", storage="f32"):
     nq = q.shape[0] // fold
-    rows64 = rows.astype(np.float64)
+    dm = parity.distance_matrix(rows, q, storage)
     for i in range(nq):
-        full = parity.full_distances(rows64, q[i * fold : (i + 1) * fold], storage)
+        full = po.least_fold(dm[i * fold : (i + 1) * fold])
         parity.check_topk(dist[i], ids[i], cnt[i], full, k, threshold=thr, keep=keep, label=f"{label} q={i}")
 
 

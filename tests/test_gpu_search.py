@@ -36,7 +36,7 @@ def test_scan_topk_matches_oracle(hvs, dtype, n, d):
     rows[9] = rows[4]  # exact tie
     q = rng.standard_normal((6, d)).astype(np.float32)
     idx = _mk(hvs, rows, dtype)
-    for k in (1, 10, 100):
+    for k in (1, 10, 100, 300) + ((1000,) if d == 100 else ()):
         dist, ids, cnt = idx.search(q, k=k, algo="scan")
         for i in range(q.shape[0]):
             full = parity.full_distances(rows, q[i], dtype)
@@ -198,4 +198,26 @@ def test_c_oracle_and_gpu_agree_at_medium_size(hvs):
     assert cnt[0] == len(ci)
     np.testing.assert_allclose(dist[0][: cnt[0]], cd, atol=1e-5)
     assert ids[0][: cnt[0]].tolist() == ci.tolist()
+    idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+def test_tiny_magnitudes_are_not_flushed(hvs, dtype):
+    """fp16 subnormals (|x| < 6.1e-5) and very small bf16 / fp32 values must take part in the dot
+    product exactly as in the oracle: cosine distance is scale-free, so a table of tiny vectors has
+    the same neighbours as its scaled-up copy."""
+    rng = np.random.default_rng(21)
+    n, d = 2000, 192
+    scale = {"f16": 2e-5, "bf16": 1e-15, "f32": 1e-15}[dtype]  # squares must stay inside the fp32 accumulator range
+    rows = (rng.standard_normal((n, d)) * scale).astype(np.float32)
+    q = rng.standard_normal((3, d)).astype(np.float32)
+    idx = _mk(hvs, rows, dtype)
+    for algo in ("scan", "mfma"):
+        dist, ids, cnt = idx.search(q, k=10, fold=1, algo=algo)
+        for i in range(3):
+            full = parity.full_distances(rows, q[i], dtype)
+            assert np.isfinite(full).sum() > n // 2
+            parity.check_topk(dist[i], ids[i], cnt[i], full, 10, label=f"tiny {dtype} {algo} q={i}")
+    dist, ids, cnt = idx.search(q, k=5, fold=3, algo="scan")
+    parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows, q, dtype), 5, label=f"tiny fold {dtype}")
     idx.close()
