@@ -144,6 +144,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     char *q_lds = smem;
     const int q_bytes = NQ * p.ld * ESZ;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_bytes + 15) & ~(size_t)15));
+    uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * 8]
 
     constexpr int SUB = 64 / LPR;     // rows per wave pass
     constexpr int RG = SCAN_R * SUB;  // rows per wave iteration
@@ -177,18 +178,20 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
 
     // This wave owns row groups gwave, gwave + nwaves, ...  With a filter (group code, row mask,
-    // tombstones) the wave first evaluates the filter of 64 of its groups at once, one group per lane,
-    // so that the dependent loads of the filter columns cost one round trip per 64 groups instead of
-    // one per group, and then visits only the groups that have a live row.
+    // tombstones) the wave first evaluates the filter of 64 of its groups at once, one group per lane
+    // (one round trip for the dependent loads of the filter columns instead of one per group), packs
+    // the surviving row numbers into a small LDS queue, and then streams only those rows, RG at a time.
     const bool filtered = !DISTONLY && (p.group_filter >= 0 || p.mask != nullptr || p.deleted != nullptr);
     const int64_t my_groups = n_groups > gwave ? (n_groups - gwave + nwaves - 1) / nwaves : 0;
+    volatile uint32_t *rowq = row_queue + wave * (64 * 8);
     for (int64_t base = 0; base < my_groups; base += 64) {
-        uint32_t mybits = 0;
-        uint64_t todo;
+        int n_items;
+        int total = 0;
         if (filtered) {
+            uint32_t mybits = 0;
             const int64_t gi = base + lane;
+            const int64_t row0 = p.row_begin + (gwave + gi * nwaves) * RG;
             if (gi < my_groups) {
-                const int64_t row0 = p.row_begin + (gwave + gi * nwaves) * RG;
 #pragma unroll
                 for (int i = 0; i < RG; i++) {
                     const int64_t row = row0 + i;
@@ -199,20 +202,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                     mybits |= (ok ? 1u : 0u) << i;
                 }
             }
-            todo = __ballot(mybits != 0);
+            // exclusive prefix sum of the live counts over the lanes
+            const int mine = __popc(mybits);
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off);
+                if (lane >= off) incl += t;
+            }
+            total = __shfl(incl, 63);
+            int pos = incl - mine;
+            wave_fence();  // earlier reads of the queue are done
+#pragma unroll
+            for (int i = 0; i < RG; i++)
+                if ((mybits >> i) & 1u) rowq[pos++] = (uint32_t)(row0 + i);
+            wave_fence();
+            n_items = (total + RG - 1) / RG;
         } else {
             const int64_t left = my_groups - base;
-            todo = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            n_items = left >= 64 ? 64 : (int)left;
         }
-      while (todo) {
-        const int j = __ffsll((unsigned long long)todo) - 1;
-        todo &= todo - 1;
-        const int64_t g = gwave + (base + j) * nwaves;
-        const uint32_t bits = filtered ? (uint32_t)__builtin_amdgcn_readlane((int)mybits, j) : 0xFFFFFFFFu;
-        const int64_t r0 = p.row_begin + g * RG + sub;
+      for (int it = 0; it < n_items; it++) {
+        int64_t rowv[SCAN_R];
         bool live[SCAN_R];
 #pragma unroll
-        for (int r = 0; r < SCAN_R; r++) live[r] = ((bits >> (r * SUB + sub)) & 1u) && (r0 + r * SUB) < p.row_end;
+        for (int r = 0; r < SCAN_R; r++) {
+            if (filtered) {
+                const int qi = it * RG + r * SUB + sub;
+                live[r] = qi < total;
+                rowv[r] = live[r] ? (int64_t)rowq[qi] : 0;
+            } else {
+                rowv[r] = p.row_begin + (gwave + (base + it) * nwaves) * RG + r * SUB + sub;
+                live[r] = rowv[r] < p.row_end;
+            }
+        }
         float acc[SCAN_R][NQ];
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++)
@@ -225,7 +248,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
 #pragma unroll
             for (int r = 0; r < SCAN_R; r++) {
                 v[r] = (u32x4){0u, 0u, 0u, 0u};
-                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + (r0 + r * SUB) * p.chunks + c);
+                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
             }
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             }
 #pragma unroll
         for (int r = 0; r < SCAN_R; r++) {
-            const int64_t row = r0 + r * SUB;
+            const int64_t row = rowv[r];
             const float inv = live[r] ? p.inv_norm[row] : 0.0f;
             float dd[NQ];
 #pragma unroll
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                     if (j >= 0 && j < p.fold) d = fminf(d, dd[t]);  // fminf drops a NaN operand: LEAST semantics
                 }
                 if (DISTONLY) {
-                    if (l == 0 && row < p.row_end) p.dist_out[row - p.row_begin] = d;
+                    if (l == 0 && live[r]) p.dist_out[row - p.row_begin] = d;
                 } else {
                     // one lane per row offers the row's key; NaN distances and filtered rows offer nothing
                     const uint64_t key = (l == 0 && live[r] && d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
@@ -508,7 +531,7 @@ static inline int round_nq(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 
 static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k) {
     size_t b = ((size_t)NQ * ld * esz + 15) & ~(size_t)15;
     b += (size_t)SCAN_WAVES * nq_out * k * 8;
-    b += (size_t)SCAN_WAVES * NQ * 4;
+    b += (size_t)SCAN_WAVES * 64 * 8 * 4;  // live-row queues
     return b;
 }
 
