@@ -49,6 +49,7 @@ SIGNATURES = {
         c_int,
         [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     ),
+    "hvs_cosine_matrix": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int]),
     "hvs_kmeans_assign": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "hvs_profile_enable": (c_int, [c_void_p, c_int]),
     "hvs_profile_get": (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),

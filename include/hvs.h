@@ -148,6 +148,19 @@ int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int6
                    float *out_dist, int64_t *out_ids, int32_t *out_count);
 
 /*
+ * Dense cosine-similarity matrix of two small row sets: out[i, j] =
+ * a_i . b_j / (|a_i| |b_j|), and 0 where either norm is 0 (scikit-learn's
+ * cosine_similarity).  a is float [m, dim], b float [n, dim], out float [m, n],
+ * all row-major without padding; on_device selects device or host pointers for
+ * all three.  Replaces the sklearn / numpy calls at HiRAG.calculate_similarity
+ * (hirag.py:571-588), validate_similarity and the synonym filter
+ * (cross_language_search/functions.py:85-113, 152-165) and the cosine block of
+ * HiRAG.dpr_recall_chunks (hirag.py:1305-1314).
+ */
+int hvs_cosine_matrix(int device_id, void *stream, const float *a, int m, const float *b, int n, int dim,
+                      float *out, int on_device);
+
+/*
  * One k-means E-step plus the partial sums of the M-step over the index's rows
  * (index dtype must be HVS_F32): assign[r] = argmin_j |x_r - c_j|^2 (lowest j
  * on ties); sums[j] += x_r, counts[j] += 1.  out_sums / out_counts may be NULL
