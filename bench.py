@@ -78,6 +78,20 @@ def cpu_baseline(n_threads: int):
     }
 
 
+def measured_traffic(rows_per_gpu, batch):
+    """HBM-side bytes per launch of the search kernel from the committed counter passes (rocprofv3
+    cannot be driven from inside this process); None when they were taken at another size."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)["mfma_search_kernel"]
+    except (OSError, KeyError, ValueError):
+        return None, None
+    if t["rows_per_gpu"] != rows_per_gpu or t["batch"] != batch or t["dim"] != DIM:
+        return None, None
+    return t["bytes"], "profiles/r1_traffic.json: " + t["how"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +166,7 @@ def main():
         per_launch_ms = kern_ms / max(kern_n, 1)
         flops = 2.0 * args.batch * (hi - lo) * DIM
         achieved = flops / (per_launch_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(hi - lo, args.batch)
         result = {
             "metric": "exact top-10 QPS, 10M x 1536 corpus",
             "value": args.batch * args.steps / elapsed,
@@ -177,12 +192,14 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "mfma_search_kernel<1>",
+                "kernel": "mfma_search_kernel<f32, fold 1>",
                 "achieved": achieved,
                 "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_src,
                 "ms_per_launch": per_launch_ms,
                 "launches": kern_n,
             },
