@@ -66,7 +66,8 @@ struct hvs_index {
     int64_t n = 0;
     int64_t cap = 0;
 
-    hvs_workspace ws[6];  // scratch buffers reused across calls: 0 queries, 1/2 candidate lists, 3 staging, 4 MFMA A operand, 5 spare
+    hvs_workspace ws[7];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
+                          // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search
 
     bool profiling = false;
     double prof_ms[HVS_PROF_COUNT] = {0};

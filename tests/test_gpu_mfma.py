@@ -83,6 +83,53 @@ def test_mfma_fold_threshold_filters(hvs, fold, dtype):
     idx.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_filtered_batch_runs_over_compacted_rows(hvs, dtype):
+    """A selective filter makes the batched path contract over a dense copy of the live rows; the answer
+    must be the one the in-epilogue filter gives (same keys, ties included) and the oracle's."""
+    rng = np.random.default_rng(77)
+    n, d = 33_333, 200
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[1000:1040] = rows[17]  # many exact ties inside one group and across groups
+    groups = (np.arange(n) % 64).astype(np.int32)
+    ext_ids = (np.arange(n, dtype=np.int64) * 3 + 5)
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows, ids=ext_ids, group_codes=groups)
+    idx.set_deleted(np.arange(3, n, 640), True)  # some of group 3's rows are tombstoned
+    q = rng.standard_normal((48, d)).astype(np.float32)
+    q[0] = rows[17]
+    keep_bits = rng.random(n) < 0.1
+    mask = np.zeros((n + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(mask, np.nonzero(keep_bits)[0] >> 5, (np.uint32(1) << (np.nonzero(keep_bits)[0] & 31).astype(np.uint32)))
+    deleted = np.zeros(n, bool)
+    deleted[np.arange(3, n, 640)] = True
+    for gf, use_mask, rb, re_ in ((3, False, 0, n), (17, False, 5001, 29_000), (-1, True, 0, n), (3, True, 100, n), (99, False, 0, n)):
+        kw = dict(k=20, group_filter=gf, row_mask=mask if use_mask else None, row_begin=rb, row_end=re_, max_distance=1.2, algo="mfma")
+        dist, ids, cnt = idx.search(q, **kw)
+        os.environ["HVS_NO_COMPACT"] = "1"
+        try:
+            d0, i0, c0 = idx.search(q, **kw)
+        finally:
+            del os.environ["HVS_NO_COMPACT"]
+        np.testing.assert_array_equal(cnt, c0)
+        np.testing.assert_array_equal(ids, i0)
+        np.testing.assert_array_equal(dist, d0)
+        keep = ~deleted
+        keep[:rb] = False
+        keep[re_:] = False
+        if gf >= 0:
+            keep &= groups == gf
+        if use_mask:
+            keep &= keep_bits
+        dm = parity.distance_matrix(rows, q, dtype)
+        for i in range(q.shape[0]):
+            parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 20, threshold=1.2, keep=keep, id_of_row=ext_ids,
+                              label=f"compacted {dtype} gf={gf} mask={use_mask} q={i}")
+        if gf == 99:
+            assert int(cnt.max()) == 0
+    idx.close()
+
+
 def test_mfma_auto_dispatch_and_synthetic(hvs):
     n, d = 40_000, 1536
     idx = hvs.HvsIndex(d, "f32")
