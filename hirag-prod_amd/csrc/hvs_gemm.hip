@@ -296,110 +296,6 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// live-row compaction for filtered batched searches
-// ---------------------------------------------------------------------------------------------
-// A selective WHERE (one workspace of many, a uri list) leaves a small fraction of the rows alive; the
-// contraction then runs over a dense copy of just those rows instead of multiplying every row and
-// discarding most scores in the epilogue.  Three small passes: count live rows per block of
-// LIVE_CHUNK rows, exclusive scan of the block counts, ordered write of the live row positions; then
-// the rows and inverse norms are gathered.  Order is preserved, so ties still go to the lower position.
-#define LIVE_THREADS 256
-#define LIVE_ITEMS 16
-#define LIVE_CHUNK (LIVE_THREADS * LIVE_ITEMS)
-
-struct LiveParams {
-    const int32_t *groups;
-    const uint32_t *mask;
-    const uint32_t *deleted;
-    int32_t group_filter;
-    int64_t row_begin, row_end;
-};
-
-__device__ __forceinline__ bool row_is_live(const LiveParams &p, int64_t row) {
-    if (row >= p.row_end) return false;
-    bool ok = true;
-    if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
-    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
-    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
-    return ok;
-}
-
-// Thread t of block b looks at rows b * LIVE_CHUNK + i * LIVE_THREADS + t (coalesced); a block's rows are
-// ordered by (i, t), which is ascending row order.
-template <bool WRITE>
-__global__ __launch_bounds__(LIVE_THREADS) void live_rows_kernel(LiveParams p, uint32_t *__restrict__ block_counts,
-                                                                 const uint32_t *__restrict__ block_offsets,
-                                                                 uint32_t *__restrict__ positions) {
-    __shared__ uint32_t wave_tot[LIVE_THREADS / 64];
-    __shared__ uint32_t running;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t base = p.row_begin + (int64_t)blockIdx.x * LIVE_CHUNK;
-    if (threadIdx.x == 0) running = WRITE ? block_offsets[blockIdx.x] : 0;
-    __syncthreads();
-    uint32_t count = 0;
-    for (int i = 0; i < LIVE_ITEMS; i++) {
-        const int64_t row = base + (int64_t)i * LIVE_THREADS + threadIdx.x;
-        const bool live = row_is_live(p, row);
-        const uint64_t b = __ballot(live);
-        if (!WRITE) {
-            count += (lane == 0) ? (uint32_t)__popcll(b) : 0u;
-        } else {
-            if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(b);
-            __syncthreads();
-            uint32_t off = running;
-            for (int w = 0; w < wave; w++) off += wave_tot[w];
-            if (live) positions[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)row;
-            __syncthreads();
-            if (threadIdx.x == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-            __syncthreads();
-        }
-    }
-    if (!WRITE) {
-        if (lane == 0) wave_tot[wave] = count;
-        __syncthreads();
-        if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    }
-}
-
-// Exclusive scan of n block counts by one block; offsets[n] = total.
-__global__ __launch_bounds__(1024) void live_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, int n) {
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = t * per, hi = min(n, lo + per);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; i++) sum += counts[i];
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
-        const uint32_t v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;
-    for (int i = lo; i < hi; i++) {
-        offsets[i] = run;
-        run += counts[i];
-    }
-    if (t == 1023) offsets[n] = part[1023];
-}
-
-// dst row i = src row positions[i] (16-byte chunks, one wave per row), with its inverse norm.
-__global__ __launch_bounds__(256) void gather_live_kernel(const char *__restrict__ src, const float *__restrict__ src_inv,
-                                                          const uint32_t *__restrict__ positions, int64_t n_live, int chunks,
-                                                          char *__restrict__ dst, float *__restrict__ dst_inv) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n_live) return;
-    const int64_t r = positions[i];
-    const uint4 *s = reinterpret_cast<const uint4 *>(src) + r * chunks;
-    uint4 *d = reinterpret_cast<uint4 *>(dst) + i * chunks;
-    for (int c = lane; c < chunks; c += 64) d[c] = s[c];
-    if (lane == 0) dst_inv[i] = src_inv[r];
-}
-
 #define HVS_COMPACT_MAX_BYTES ((size_t)16 << 30)  // largest dense copy a filtered search may make
 
 // ---------------------------------------------------------------------------------------------
@@ -491,21 +387,13 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.row_end = row_end;
 
     // A WHERE on the group code or a row bitmask: count the live rows and, when they are a minority,
-    // contract over a dense copy of them (tombstones alone are sparse and stay in the epilogue).
+    // contract over a dense copy of them (tombstones alone are sparse and stay in the epilogue): the
+    // contraction then costs n_live instead of n rows, and the copy is 2 * n_live * row bytes of traffic.
     const int64_t n_range = row_end - row_begin;
     if ((group_filter >= 0 || d_mask) && n_range >= 4 * BN && row_end <= (int64_t)0xFFFFFFFFll && !getenv("HVS_NO_COMPACT")) {
-        LiveParams lp{idx->groups, d_mask, p.deleted, group_filter, row_begin, row_end};
-        const int nb = (int)((n_range + LIVE_CHUNK - 1) / LIVE_CHUNK);
-        const size_t o_off = ((size_t)nb * 4 + 255) & ~(size_t)255;
-        void *cw = nullptr;
-        HVS_TRY(hvs_ws_get(idx, 5, o_off + (size_t)(nb + 1) * 4, &cw));
-        uint32_t *counts = (uint32_t *)cw, *offsets = (uint32_t *)((char *)cw + o_off);
-        live_rows_kernel<false><<<nb, LIVE_THREADS, 0, idx->stream>>>(lp, counts, nullptr, nullptr);
-        live_scan_kernel<<<1, 1024, 0, idx->stream>>>(counts, offsets, nb);
-        HVS_HIP(hipGetLastError());
+        hvs_live_params lp{idx->groups, d_mask, p.deleted, group_filter, row_begin, row_end};
         uint32_t n_live = 0;
-        HVS_HIP(hipMemcpyAsync(&n_live, offsets + nb, 4, hipMemcpyDeviceToHost, idx->stream));
-        HVS_HIP(hipStreamSynchronize(idx->stream));
+        HVS_TRY(hvs_live_count(idx, lp, &n_live));
         const size_t pos_bytes = ((size_t)n_live * 4 + 255) & ~(size_t)255;
         const size_t copy_bytes = (size_t)n_live * ld_bytes;
         if ((int64_t)n_live * 2 <= n_range && copy_bytes <= HVS_COMPACT_MAX_BYTES) {
@@ -515,10 +403,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
             float *c_inv = (float *)((char *)cr + pos_bytes);
             char *c_rows = (char *)cr + 2 * pos_bytes;
             if (n_live > 0) {
-                live_rows_kernel<true><<<nb, LIVE_THREADS, 0, idx->stream>>>(lp, nullptr, offsets, positions);
-                gather_live_kernel<<<(n_live + 3) / 4, 256, 0, idx->stream>>>((const char *)idx->rows, idx->inv_norm, positions,
-                                                                              n_live, ld_bytes / 16, c_rows, c_inv);
-                HVS_HIP(hipGetLastError());
+                HVS_TRY(hvs_live_write(idx, lp, positions));
+                HVS_TRY(hvs_live_gather(idx, positions, n_live, c_rows, c_inv));
             }
             p.X = c_rows;
             p.inv_norm = c_inv;

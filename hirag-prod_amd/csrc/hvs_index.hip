@@ -125,11 +125,29 @@ __global__ void gather_kernel(const T *__restrict__ rows, const int64_t *__restr
     }
 }
 
-__global__ void set_deleted_kernel(uint32_t *bits, const int64_t *positions, int64_t n, int deleted) {
+// flips counts the bits that actually changed, so that the index's tombstone count stays exact when a
+// position is deleted twice or restored without having been deleted
+__global__ void set_deleted_kernel(uint32_t *bits, const int64_t *positions, int64_t n, int deleted, unsigned long long *flips) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = positions[i];
-        if (deleted) atomicOr(&bits[p >> 5], 1u << (p & 31));
-        else atomicAnd(&bits[p >> 5], ~(1u << (p & 31)));
+        const uint32_t bit = 1u << (p & 31);
+        const uint32_t old = deleted ? atomicOr(&bits[p >> 5], bit) : atomicAnd(&bits[p >> 5], ~bit);
+        if (((old & bit) != 0) != (deleted != 0)) atomicAdd(flips, 1ull);
+    }
+}
+
+__global__ void unpack_deleted_kernel(const uint32_t *bits, int64_t first, int64_t n, uint8_t *out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = first + i;
+        out[i] = bits ? (uint8_t)((bits[p >> 5] >> (p & 31)) & 1u) : (uint8_t)0;
+    }
+}
+
+__global__ void gather_meta_kernel(const int64_t *ids, const int32_t *groups, const uint32_t *positions, int64_t n,
+                                   int64_t *out_ids, int32_t *out_groups) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        out_ids[i] = ids[positions[i]];
+        out_groups[i] = groups[positions[i]];
     }
 }
 
@@ -175,6 +193,142 @@ int hvs_prof_end(hvs_index *idx, int which) {
     HVS_HIP(hipEventElapsedTime(&ms, idx->ev0, idx->ev1));
     idx->prof_ms[which] += ms;
     idx->prof_launches[which] += 1;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// live-row lists
+// ---------------------------------------------------------------------------
+// Ordered list of the rows that pass a filter (group code, bitmask, tombstones, row range), used by
+// filtered batched searches (which then contract over a dense copy of just those rows) and by
+// tombstone compaction.  Three small passes: count live rows per block of
+// LIVE_CHUNK rows, exclusive scan of the block counts, ordered write of the live row positions; then
+// the rows and inverse norms are gathered.  Order is preserved, so ties still go to the lower position.
+#define LIVE_THREADS 256
+#define LIVE_ITEMS 16
+#define LIVE_CHUNK (LIVE_THREADS * LIVE_ITEMS)
+
+__device__ __forceinline__ bool row_is_live(const hvs_live_params &p, int64_t row) {
+    if (row >= p.row_end) return false;
+    bool ok = true;
+    if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+    return ok;
+}
+
+// Thread t of block b looks at rows b * LIVE_CHUNK + i * LIVE_THREADS + t (coalesced); a block's rows are
+// ordered by (i, t), which is ascending row order.
+template <bool WRITE>
+__global__ __launch_bounds__(LIVE_THREADS) void live_rows_kernel(hvs_live_params p, uint32_t *__restrict__ block_counts,
+                                                                 const uint32_t *__restrict__ block_offsets,
+                                                                 uint32_t *__restrict__ positions) {
+    __shared__ uint32_t wave_tot[LIVE_THREADS / 64];
+    __shared__ uint32_t running;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = p.row_begin + (int64_t)blockIdx.x * LIVE_CHUNK;
+    if (threadIdx.x == 0) running = WRITE ? block_offsets[blockIdx.x] : 0;
+    __syncthreads();
+    uint32_t count = 0;
+    for (int i = 0; i < LIVE_ITEMS; i++) {
+        const int64_t row = base + (int64_t)i * LIVE_THREADS + threadIdx.x;
+        const bool live = row_is_live(p, row);
+        const uint64_t b = __ballot(live);
+        if (!WRITE) {
+            count += (lane == 0) ? (uint32_t)__popcll(b) : 0u;
+        } else {
+            if (lane == 0) wave_tot[wave] = (uint32_t)__popcll(b);
+            __syncthreads();
+            uint32_t off = running;
+            for (int w = 0; w < wave; w++) off += wave_tot[w];
+            if (live) positions[off + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)row;
+            __syncthreads();
+            if (threadIdx.x == 0) running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            __syncthreads();
+        }
+    }
+    if (!WRITE) {
+        if (lane == 0) wave_tot[wave] = count;
+        __syncthreads();
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    }
+}
+
+// Exclusive scan of n block counts by one block; offsets[n] = total.
+__global__ __launch_bounds__(1024) void live_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, int n) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = t * per, hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += counts[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int i = lo; i < hi; i++) {
+        offsets[i] = run;
+        run += counts[i];
+    }
+    if (t == 1023) offsets[n] = part[1023];
+}
+
+// dst row i = src row positions[i] (16-byte chunks, one wave per row), with its inverse norm.
+__global__ __launch_bounds__(256) void gather_live_kernel(const char *__restrict__ src, const float *__restrict__ src_inv,
+                                                          const uint32_t *__restrict__ positions, int64_t n_live, int chunks,
+                                                          char *__restrict__ dst, float *__restrict__ dst_inv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_live) return;
+    const int64_t r = positions[i];
+    const uint4 *s = reinterpret_cast<const uint4 *>(src) + r * chunks;
+    uint4 *d = reinterpret_cast<uint4 *>(dst) + i * chunks;
+    for (int c = lane; c < chunks; c += 64) d[c] = s[c];
+    if (lane == 0) dst_inv[i] = src_inv[r];
+}
+
+
+int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live) {
+    *n_live = 0;
+    const int64_t n_range = lp.row_end - lp.row_begin;
+    if (n_range <= 0) return 0;
+    HVS_REQUIRE(lp.row_end <= (int64_t)0xFFFFFFFFll, "row positions beyond 2^32-1");
+    const int nb = (int)((n_range + LIVE_CHUNK - 1) / LIVE_CHUNK);
+    const size_t o_off = ((size_t)nb * 4 + 255) & ~(size_t)255;
+    void *cw = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 5, o_off + (size_t)(nb + 1) * 4, &cw));
+    uint32_t *counts = (uint32_t *)cw, *offsets = (uint32_t *)((char *)cw + o_off);
+    live_rows_kernel<false><<<nb, LIVE_THREADS, 0, idx->stream>>>(lp, counts, nullptr, nullptr);
+    live_scan_kernel<<<1, 1024, 0, idx->stream>>>(counts, offsets, nb);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipMemcpyAsync(n_live, offsets + nb, 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
+// Must follow hvs_live_count with the same parameters (it uses the block offsets that call left in
+// workspace 5); positions needs room for the count it returned.
+int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *positions) {
+    const int64_t n_range = lp.row_end - lp.row_begin;
+    if (n_range <= 0) return 0;
+    const int nb = (int)((n_range + LIVE_CHUNK - 1) / LIVE_CHUNK);
+    const size_t o_off = ((size_t)nb * 4 + 255) & ~(size_t)255;
+    const uint32_t *offsets = (const uint32_t *)((char *)idx->ws[5].ptr + o_off);
+    live_rows_kernel<true><<<nb, LIVE_THREADS, 0, idx->stream>>>(lp, nullptr, offsets, positions);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv) {
+    if (n_live <= 0) return 0;
+    gather_live_kernel<<<(unsigned)((n_live + 3) / 4), 256, 0, idx->stream>>>((const char *)idx->rows, idx->inv_norm, positions,
+                                                                             n_live, idx->ld * idx->elem_size / 16, dst_rows, dst_inv);
+    HVS_HIP(hipGetLastError());
     return 0;
 }
 
@@ -411,13 +565,114 @@ extern "C" int hvs_index_set_deleted(hvs_index *idx, const int64_t *positions, i
         HVS_HIP(hipMemsetAsync(idx->deleted, 0, words * 4, idx->stream));
     }
     void *stage = nullptr;
-    HVS_TRY(hvs_ws_get(idx, 3, (size_t)n * 8, &stage));
+    const size_t cnt_off = ((size_t)n * 8 + 255) & ~(size_t)255;
+    HVS_TRY(hvs_ws_get(idx, 3, cnt_off + 8, &stage));
+    unsigned long long *d_flips = (unsigned long long *)((char *)stage + cnt_off);
     HVS_HIP(hipMemcpyAsync(stage, positions, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
-    set_deleted_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->deleted, (const int64_t *)stage, n, deleted);
+    HVS_HIP(hipMemsetAsync(d_flips, 0, 8, idx->stream));
+    set_deleted_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->deleted, (const int64_t *)stage, n, deleted, d_flips);
     HVS_HIP(hipGetLastError());
+    unsigned long long flips = 0;
+    HVS_HIP(hipMemcpyAsync(&flips, d_flips, 8, hipMemcpyDeviceToHost, idx->stream));
     HVS_HIP(hipStreamSynchronize(idx->stream));
-    idx->n_deleted += deleted ? n : -n;
-    if (idx->n_deleted < 0) idx->n_deleted = 0;
+    idx->n_deleted += deleted ? (int64_t)flips : -(int64_t)flips;
+    return 0;
+}
+
+extern "C" int hvs_index_deleted_count(hvs_index *idx, int64_t *out_rows) {
+    HVS_REQUIRE(idx && out_rows, "hvs_index_deleted_count: NULL argument");
+    *out_rows = idx->n_deleted;
+    return 0;
+}
+
+extern "C" int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64_t *ids, int32_t *group_codes,
+                                uint8_t *deleted) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_export: idx is NULL");
+    HVS_REQUIRE(first >= 0 && n >= 0 && first + n <= idx->n, "hvs_index_export: rows [%lld, %lld) outside [0, %lld)",
+                (long long)first, (long long)(first + n), (long long)idx->n);
+    if (n == 0) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    hipStream_t s = idx->stream;
+    if (rows) {
+        const size_t row_bytes = (size_t)idx->dim * idx->elem_size, pitch = (size_t)idx->ld * idx->elem_size;
+        HVS_HIP(hipMemcpy2DAsync(rows, row_bytes, (const char *)idx->rows + (size_t)first * pitch, pitch, row_bytes, (size_t)n,
+                                 hipMemcpyDeviceToHost, s));
+    }
+    if (ids) HVS_HIP(hipMemcpyAsync(ids, idx->ids + first, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (group_codes) HVS_HIP(hipMemcpyAsync(group_codes, idx->groups + first, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (deleted) {
+        void *stage = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 3, (size_t)n, &stage));
+        unpack_deleted_kernel<<<grid_for(n), 256, 0, s>>>(idx->n_deleted > 0 ? idx->deleted : nullptr, first, n, (uint8_t *)stage);
+        HVS_HIP(hipGetLastError());
+        HVS_HIP(hipMemcpyAsync(deleted, stage, (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    HVS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_compact: idx is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    if (idx->n_deleted > 0 && idx->n > 0) {
+        hvs_live_params lp{idx->groups, nullptr, idx->deleted, -1, 0, idx->n};
+        uint32_t n_live = 0;
+        HVS_TRY(hvs_live_count(idx, lp, &n_live));
+        const size_t pitch = (size_t)idx->ld * idx->elem_size;
+        const int64_t cap = n_live > 1024 ? (int64_t)n_live : 1024;
+        uint32_t *positions = nullptr;
+        char *rows = nullptr;
+        float *inv = nullptr;
+        int64_t *ids = nullptr;
+        int32_t *groups = nullptr;
+        int rc = 0;
+        do {  // new arrays sized for the survivors; the old ones are released only when every copy has succeeded
+            hipError_t e;
+            if ((e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4)) != hipSuccess || (e = hipMalloc((void **)&rows, (size_t)cap * pitch)) != hipSuccess ||
+                (e = hipMalloc((void **)&inv, (size_t)cap * 4)) != hipSuccess || (e = hipMalloc((void **)&ids, (size_t)cap * 8)) != hipSuccess ||
+                (e = hipMalloc((void **)&groups, (size_t)cap * 4)) != hipSuccess) {
+                hvs_set_error("hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
+                rc = 1;
+                break;
+            }
+            if (n_live > 0) {
+                if ((rc = hvs_live_write(idx, lp, positions)) != 0) break;
+                if ((rc = hvs_live_gather(idx, positions, n_live, rows, inv)) != 0) break;
+                gather_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->ids, idx->groups, positions, n_live, ids, groups);
+                if (renumber_ids) fill_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(ids, groups, n_live, 0, 0, 0, nullptr, groups);
+            }
+            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(idx->stream)) != hipSuccess) {
+                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
+                rc = 1;
+            }
+        } while (0);
+        (void)hipFree(positions);
+        if (rc != 0) {
+            (void)hipFree(rows);
+            (void)hipFree(inv);
+            (void)hipFree(ids);
+            (void)hipFree(groups);
+            return rc;
+        }
+        (void)hipFree(idx->rows);
+        (void)hipFree(idx->inv_norm);
+        (void)hipFree(idx->ids);
+        (void)hipFree(idx->groups);
+        (void)hipFree(idx->deleted);
+        idx->rows = rows;
+        idx->inv_norm = inv;
+        idx->ids = ids;
+        idx->groups = groups;
+        idx->deleted = nullptr;
+        idx->n_deleted = 0;
+        idx->n = n_live;
+        idx->cap = cap;
+    } else if (renumber_ids && idx->n > 0) {
+        fill_meta_kernel<<<grid_for(idx->n), 256, 0, idx->stream>>>(idx->ids, idx->groups, idx->n, 0, 0, 0, nullptr, idx->groups);
+        HVS_HIP(hipGetLastError());
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    if (out_rows) *out_rows = idx->n;
     return 0;
 }
 

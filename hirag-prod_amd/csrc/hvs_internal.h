@@ -82,6 +82,18 @@ int hvs_ws_get(hvs_index *idx, int slot, size_t bytes, void **out);
 int hvs_prof_begin(hvs_index *idx);
 int hvs_prof_end(hvs_index *idx, int which);
 
+// Rows of [row_begin, row_end) that pass a filter, as an ordered list of positions (hvs_index.hip).
+struct hvs_live_params {
+    const int32_t *groups;
+    const uint32_t *mask;     // optional: bit set = row may be returned
+    const uint32_t *deleted;  // optional: bit set = row deleted
+    int32_t group_filter;     // -1 = any group
+    int64_t row_begin, row_end;
+};
+int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live);          // synchronises the stream
+int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *positions);        // after hvs_live_count
+int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv);
+
 static inline int hvs_elem_size(int dtype) { return dtype == HVS_F32 ? 4 : 2; }
 
 // ---------------------------------------------------------------------------

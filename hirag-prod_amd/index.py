@@ -267,6 +267,49 @@ class HvsIndex:
         check(self._lib.hvs_timer_stop(self._h, ctypes.byref(ms)))
         return ms.value
 
+    # -- tombstones, compaction, snapshots -------------------------------------------------------------
+    def deleted_count(self) -> int:
+        n = ctypes.c_int64(0)
+        check(self._lib.hvs_index_deleted_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def compact(self, renumber_ids: bool = False) -> int:
+        """Drop deleted rows and close the gaps (order kept); returns the new row count.  Row
+        positions change: position i afterwards is the i-th live row before.  Ids move with their
+        rows, or become the new positions when ``renumber_ids`` is set."""
+        n = ctypes.c_int64(0)
+        with self._lock:
+            check(self._lib.hvs_index_compact(self._h, 1 if renumber_ids else 0, ctypes.byref(n)))
+        return n.value
+
+    def export(self, first: int = 0, n: Optional[int] = None):
+        """Rows ``[first, first + n)`` as stored -> ``(rows, ids, group_codes, deleted)``; ``rows`` is
+        float32 / float16, or uint16 bit patterns for a bf16 index."""
+        total = len(self)
+        n = total - first if n is None else int(n)
+        np_dtype = {"f32": np.float32, "f16": np.float16, "bf16": np.uint16}[self.dtype]
+        rows = np.empty((n, self.dim), dtype=np_dtype)
+        ids = np.empty(n, dtype=np.int64)
+        groups = np.empty(n, dtype=np.int32)
+        deleted = np.empty(n, dtype=np.uint8)
+        with self._lock:
+            check(self._lib.hvs_index_export(self._h, int(first), n, _np_ptr(rows), _np_ptr(ids), _np_ptr(groups), _np_ptr(deleted)))
+        return rows, ids, groups, deleted.astype(bool)
+
+    def save(self, path: str) -> None:
+        """Write the table to one snapshot file (``snapshot.write_index``)."""
+        from .snapshot import write_index
+
+        write_index(self, path)
+
+    @classmethod
+    def load(cls, path: str, device: int = 0, stream: Optional[int] = None) -> "HvsIndex":
+        """Rebuild a table from a snapshot file: stored values go back bit for bit (no re-rounding),
+        inverse norms are recomputed on the device, tombstones are restored."""
+        from .snapshot import read_index
+
+        return read_index(path, lambda dim, dtype: cls(dim, dtype, device=device, stream=stream))
+
 
 def merge_topk(dist, ids, count, k: int, stream: int = 0):
     """Merge ``[nq, P, k]`` per-shard candidate lists (torch tensors on one GPU) into ``[nq, k]``."""

@@ -538,6 +538,124 @@ class HipVectorStore(BaseVDB):
             out.append(rec)
         return out
 
+    # -- compaction and snapshots (the table outlives deletes and restarts) --------------------------
+    async def compact(self, table_name: Optional[str] = None) -> Dict[str, int]:
+        """Reclaim the rows ``clean_table`` deleted: tombstoned rows leave HBM and the host lists, the
+        survivors keep their order.  Returns ``{table: live rows}`` for the tables compacted."""
+        names = [table_name] if table_name else list(self.tables)
+        out: Dict[str, int] = {}
+        async with self._lock:
+            for name in names:
+                table = self.get_model(name)
+                n = len(table.rows)
+                keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
+                if len(keep) != n:
+                    if table.index is not None:
+                        left = await asyncio.to_thread(table.index.compact, True)
+                        assert left == len(keep), "host rows and device rows out of step"
+                    table.rows = [table.rows[pos] for pos in keep]
+                    for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
+                        setattr(table, col, getattr(table, col)[:n][keep].copy())
+                    table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
+                out[name] = len(table.rows)
+        return out
+
+    @staticmethod
+    def _json_default(v):
+        if isinstance(v, datetime):
+            return {"__datetime__": v.isoformat()}
+        if isinstance(v, (np.integer,)):
+            return int(v)
+        if isinstance(v, (np.floating,)):
+            return float(v)
+        if isinstance(v, np.ndarray):
+            return v.tolist()
+        raise TypeError(f"cannot snapshot a value of type {type(v).__name__}")
+
+    @staticmethod
+    def _json_hook(d):
+        if len(d) == 1 and "__datetime__" in d:
+            return datetime.fromisoformat(d["__datetime__"])
+        return d
+
+    async def save(self, directory: str) -> None:
+        """Write the whole store under ``directory``: ``store.json`` (settings and the filter-code
+        dictionaries), per table ``<name>.rows.jsonl`` (metadata rows, ``null`` for a deleted row;
+        ``datetime`` values are tagged, other non-JSON values are refused) and, for embedded tables,
+        ``<name>.hvs`` (``snapshot.write_index``: the vectors exactly as stored)."""
+        import json
+        import os
+
+        from .snapshot import write_index
+
+        os.makedirs(directory, exist_ok=True)
+        async with self._lock:
+            def keys_by_code(mapping):
+                keys = [None] * len(mapping)
+                for key, code in mapping.items():
+                    keys[code] = list(key) if isinstance(key, tuple) else key
+                return keys
+
+            meta = {"format": 1, "vector_type": self.vector_type, "embedding_dimension": self.embedding_dimension,
+                    "workspaces": keys_by_code(self._ws_codes), "knowledge_bases": keys_by_code(self._kb_codes),
+                    "uris": keys_by_code(self._uri_codes), "groups": keys_by_code(self._group_codes),
+                    "tables": {name: {"rows": len(t.rows), "indexed": t.index is not None} for name, t in self.tables.items()}}
+            for name, table in self.tables.items():
+                with open(os.path.join(directory, f"{name}.rows.jsonl"), "w") as fh:
+                    for row in table.rows:
+                        fh.write(json.dumps(row, default=self._json_default) + "\n")
+                if table.index is not None:
+                    await asyncio.to_thread(write_index, table.index, os.path.join(directory, f"{name}.hvs"))
+            with open(os.path.join(directory, "store.json"), "w") as fh:  # last: its presence marks a complete snapshot
+                json.dump(meta, fh)
+
+    @classmethod
+    async def load(cls, directory: str, embedding_func: Optional[Callable], **kwargs) -> "HipVectorStore":
+        """Rebuild a store from ``save``'s files; ``kwargs`` as for the constructor (``vector_type`` and
+        ``embedding_dimension`` come from the snapshot)."""
+        import json
+        import os
+
+        from .snapshot import read_index
+
+        with open(os.path.join(directory, "store.json")) as fh:
+            meta = json.load(fh)
+        if meta.get("format") != 1:
+            raise ValueError(f"{directory}: unknown store snapshot format {meta.get('format')!r}")
+        kwargs.pop("vector_type", None)
+        kwargs.pop("embedding_dimension", None)
+        store = cls(embedding_func, vector_type=meta["vector_type"], embedding_dimension=meta["embedding_dimension"], **kwargs)
+        store._ws_codes = {k: i for i, k in enumerate(meta["workspaces"])}
+        store._kb_codes = {k: i for i, k in enumerate(meta["knowledge_bases"])}
+        store._uri_codes = {k: i for i, k in enumerate(meta["uris"])}
+        store._group_codes = {tuple(k): i for i, k in enumerate(meta["groups"])}
+        for name, info in meta["tables"].items():
+            table = store.get_model(name)
+            with open(os.path.join(directory, f"{name}.rows.jsonl")) as fh:
+                table.rows = [json.loads(line, object_hook=cls._json_hook) for line in fh]
+            if len(table.rows) != info["rows"]:
+                raise ValueError(f"{directory}: {name}.rows.jsonl holds {len(table.rows)} rows, store.json says {info['rows']}")
+            n = len(table.rows)
+            table._grow(n)
+            for pos, row in enumerate(table.rows):
+                if row is None:
+                    continue
+                ws, kb = row.get("workspaceId"), row.get("knowledgeBaseId")
+                if table.has_vector:
+                    table.group[pos] = store._group_codes[(ws, kb)]
+                table.ws_code[pos] = store._ws_codes[ws]
+                table.kb_code[pos] = store._kb_codes[kb]
+                table.uri_code[pos] = store._uri_codes[row.get("uri")]
+                table.private[pos] = bool(row.get("private", False))
+                table.live[pos] = True
+                table.pk_map[tuple(row.get(c) for c in table.pk)] = pos
+            if info["indexed"]:
+                table.index = await asyncio.to_thread(
+                    read_index, os.path.join(directory, f"{name}.hvs"), lambda dim, dtype: store._make_index(dim))
+                if len(table.index) != n or table.index.dtype != store.dtype:
+                    raise ValueError(f"{directory}: {name}.hvs does not match the store ({len(table.index)} rows, {table.index.dtype})")
+        return store
+
     # -- delegated (graph side, not on the dense-retrieval path) -------------------------------------
     def __getattr__(self, name):
         if name in ("upsert_graph", "query_node", "pagerank_top_chunks_with_reset", "upsert_file_from_metadata"):

@@ -85,6 +85,32 @@ int hvs_index_update(hvs_index *idx, const int64_t *positions, const void *rows,
  */
 int hvs_index_set_deleted(hvs_index *idx, const int64_t *positions, int64_t n, int deleted);
 
+/* Number of rows currently marked deleted (tombstones not yet compacted away). */
+int hvs_index_deleted_count(hvs_index *idx, int64_t *out_rows);
+
+/*
+ * Drop every deleted row and close the gaps, keeping the order of the
+ * survivors; row positions change (position i afterwards = the i-th live row
+ * before), ids and group codes move with their rows.  The space a DELETE of
+ * PGVector.clean_table (pgvector.py:452-473) leaves is reclaimed by PostgreSQL's
+ * vacuum; this is the same step for the HBM-resident table.  With renumber_ids
+ * the ids become the new positions (for callers that use positions as ids).
+ * *out_rows (may be NULL) receives the new row count.
+ */
+int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
+
+/*
+ * Copy rows [first, first + n) to HOST buffers, for snapshots: rows as stored
+ * (index dtype, n * dim elements, no padding; feeding them back through
+ * hvs_index_add with src_dtype = the index dtype reproduces the table bit for
+ * bit), ids, group codes, and one byte per row that is 1 for a deleted row.
+ * Any output may be NULL.  The reference keeps its table in PostgreSQL and has
+ * no counterpart; the format the vectors take there is the `vector` /
+ * `halfvec` column of schema/vector_config.py:11.
+ */
+int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64_t *ids,
+                     int32_t *group_codes, uint8_t *deleted);
+
 /*
  * Fill the index with n synthetic rows generated on the device: row r (global
  * number first_global_row + r), column c is ((sum of the four 16-bit fields of

@@ -23,7 +23,10 @@ class OracleIndex:
 
     def add(self, rows, ids=None, group_codes=None):
         first = len(self)
-        rows = np.asarray(rows, dtype=np.float32)
+        rows = np.asarray(rows)
+        if rows.dtype == np.uint16:  # bf16 bit patterns, as export() hands them out
+            rows = (rows.astype(np.uint32) << 16).view(np.float32)
+        rows = rows.astype(np.float32)
         self.rows = np.concatenate([self.rows, rows])
         g = np.zeros(rows.shape[0], np.int32) if group_codes is None else np.asarray(group_codes, np.int32)
         self.groups = np.concatenate([self.groups, g])
@@ -67,6 +70,26 @@ class OracleIndex:
 
     def gather(self, positions):
         return po.round_storage(self.rows[np.asarray(positions, dtype=np.int64)], self.dtype).astype(np.float32)
+
+    def deleted_count(self):
+        return int(self.deleted.sum())
+
+    def compact(self, renumber_ids=False):
+        keep = ~self.deleted
+        self.rows, self.groups, self.deleted = self.rows[keep], self.groups[keep], np.zeros(int(keep.sum()), bool)
+        return len(self)
+
+    def export(self, first=0, n=None):
+        n = len(self) - first if n is None else n
+        sl = slice(first, first + n)
+        stored = po.round_storage(self.rows[sl], self.dtype)
+        if self.dtype == "bf16":
+            stored = (stored.astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+        elif self.dtype == "f16":
+            stored = stored.astype(np.float16)
+        else:
+            stored = stored.astype(np.float32)
+        return stored, np.arange(first, first + n, dtype=np.int64), self.groups[sl].copy(), self.deleted[sl].copy()
 
     def close(self):
         pass

@@ -181,5 +181,72 @@ async def scenario_many_embeddings(store, storage):
     same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
 
 
+async def scenario_compact_and_snapshot(store, load_store, storage, directory):
+    """Deletes are reclaimed by ``compact`` and the store survives ``save`` / ``load``: every query
+    answers as before (same keys, same distances bit for bit -- the stored values do not change)."""
+    from datetime import datetime
+
+    await store._init_vdb(embedding_dimension=DIM)
+    n = 150
+    props = [chunk_props(i, ws="ws1" if i % 3 else "ws2", private=(i % 4 == 0)) for i in range(n)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts, props, "Chunks")
+    trip = [{"source": f"s{i}", "target": f"t{i}", "description": f"relation {i}", "fileName": "f", "uri": "s3://bucket/t.pdf",
+             "documentId": "d", "knowledgeBaseId": "kb1", "workspaceId": "ws1"} for i in range(40)]
+    await store.upsert_texts([t["description"] for t in trip], trip, "Triplets")
+    await store.upsert_file({"documentKey": "file-1", "knowledgeBaseId": "kb1", "workspaceId": "ws1", "fileName": "a.pdf",
+                             "uri": "s3://bucket/a.pdf"})
+    assert await store.clean_table("Chunks", {"uri": "s3://bucket/file1.pdf"}) is True
+    assert await store.clean_table("Triplets", {"description": "relation 7"}) is True
+
+    async def probe(s):
+        out = []
+        out.append(await s.query(["text ws1 kb1 10", "text ws1 kb1 20"], "ws1", "kb1", "Chunks", topk=25, distance_threshold=1.5,
+                                 columns_to_select=["documentKey", "chunkIdx"]))
+        out.append(await s.query("text ws2 kb1 3", "ws2", "kb1", "Chunks", topk=5, distance_threshold=1.9, require_access="public"))
+        out.append(await s.query("relation 8", "ws1", "kb1", "Triplets", topk=8, distance_threshold=1.9,
+                                 columns_to_select=["description"]))
+        out.append(await s.query_by_keys([props[2]["documentKey"], props[5]["documentKey"]], "ws1", "kb1", "Chunks",
+                                         columns_to_select=["documentKey", "vector"]))
+        out.append(sorted(await s.get_existing_document_keys("s3://bucket/file2.pdf", "ws1", "kb1", "Chunks")))
+        return out
+
+    def strip(results):  # updatedAt differs per object identity only; compare everything else
+        return [[{k: v for k, v in r.items()} for r in res] if res and isinstance(res[0], dict) else res for res in results]
+
+    before = strip(await probe(store))
+    assert len(before[0]) == 25 and before[2][0]["description"] == "relation 8"
+    alive = sum(1 for p in props if not p["uri"].endswith("file1.pdf"))
+    assert len(store.tables["Chunks"].index) == n
+    left = await store.compact()
+    assert left["Chunks"] == alive and left["Triplets"] == 39 and left["Files"] == 1
+    assert len(store.tables["Chunks"].index) == alive
+    assert strip(await probe(store)) == before
+    # a key that was deleted can come back, and lands after the survivors
+    back = [p for p in props if p["uri"].endswith("file1.pdf")][:2]
+    await store.upsert_texts([p["text"] for p in back], back, "Chunks")
+    assert len(store.tables["Chunks"].index) == alive + 2
+    res = await store.query(back[0]["text"], back[0]["workspaceId"], "kb1", "Chunks", topk=1, topn=1)
+    assert res[0]["documentKey"] == back[0]["documentKey"] and res[0]["distance"] < 1e-3
+    assert await store.clean_table("Chunks", {"documentKey": back[1]["documentKey"]}) is True  # a tombstone travels too
+
+    after_reinsert = strip(await probe(store))
+    await store.save(directory)
+    again = await load_store(directory)
+    assert again.vector_type == store.vector_type and again.embedding_dimension == DIM
+    assert strip(await probe(again)) == after_reinsert
+    row = (await again.query_by_keys([props[2]["documentKey"]], "ws1", "kb1", "Chunks"))[0]
+    assert isinstance(row["updatedAt"], datetime) and row["chunkIdx"] == 2
+    # the loaded store keeps first-write-wins and accepts new rows in new and old workspaces
+    await again.upsert_texts(["changed"], [props[2]], "Chunks")
+    assert (await again.query_by_keys([props[2]["documentKey"]], "ws1", "kb1", "Chunks"))[0]["text"] == props[2]["text"]
+    fresh = chunk_props(999, ws="ws9")
+    await again.upsert_texts([fresh["text"]], [fresh], "Chunks")
+    res = await again.query(fresh["text"], "ws9", "kb1", "Chunks", topk=3, topn=3)
+    assert [r["documentKey"] for r in res] == [fresh["documentKey"]]
+    assert await again.query(back[1]["text"], back[1]["workspaceId"], "kb1", "Chunks", topk=1, topn=1, distance_threshold=1e-3) == []
+    again.close()
+
+
 def run(coro):
     return asyncio.run(coro)

@@ -221,3 +221,79 @@ def test_tiny_magnitudes_are_not_flushed(hvs, dtype):
     dist, ids, cnt = idx.search(q, k=5, fold=3, algo="scan")
     parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows, q, dtype), 5, label=f"tiny fold {dtype}")
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_tombstones_compaction_and_snapshot(hvs, dtype, tmp_path):
+    """Deleted rows stay out of results, compaction removes them without changing any answer, and a
+    snapshot file brings back the same bits (rows, ids, group codes, tombstones)."""
+    rng = np.random.default_rng(31)
+    n, d = 5000, 72  # 72 elements: a padded row pitch for every storage type
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    ext_ids = rng.permutation(n).astype(np.int64) + 10_000
+    groups = (np.arange(n) % 9).astype(np.int32)
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows, ids=ext_ids, group_codes=groups)
+    gone = rng.choice(n, 700, replace=False)
+    idx.set_deleted(gone, True)
+    assert idx.deleted_count() == 700
+    idx.set_deleted(gone[:50], True)  # deleting twice does not count twice
+    assert idx.deleted_count() == 700
+    idx.set_deleted(np.array([n - 1 if (n - 1) not in gone else n - 2]), False)  # restoring a live row changes nothing
+    assert idx.deleted_count() == 700
+    idx.set_deleted(gone[:100], False)
+    assert idx.deleted_count() == 600
+    dead = np.zeros(n, bool)
+    dead[gone[100:]] = True
+    q = rng.standard_normal((3, d)).astype(np.float32)
+
+    def answers(ix):
+        return [ix.search(q, k=20, algo="scan"), ix.search(q, k=20, group_filter=4, algo="scan"), ix.search(np.tile(q, (16, 1)), k=7, algo="mfma")]
+
+    before = answers(idx)
+    for i in range(3):
+        parity.check_topk(before[0][0][i], before[0][1][i], before[0][2][i], parity.full_distances(rows, q[i], dtype), 20,
+                          keep=~dead, id_of_row=ext_ids, label=f"tombstones {dtype}")
+    # export: the stored bits, unpadded
+    raw, ids, grp, dl = idx.export()
+    stored = po.round_storage(rows, dtype)
+    exp_raw = parity.bf16_bits(rows) if dtype == "bf16" else stored.astype(raw.dtype)
+    np.testing.assert_array_equal(raw, exp_raw)
+    np.testing.assert_array_equal(ids, ext_ids)
+    np.testing.assert_array_equal(grp, groups)
+    np.testing.assert_array_equal(dl, dead)
+    part = idx.export(1234, 100)
+    np.testing.assert_array_equal(part[0], exp_raw[1234:1334])
+    np.testing.assert_array_equal(part[3], dead[1234:1334])
+
+    path = str(tmp_path / f"t_{dtype}.hvs")
+    idx.save(path)
+    twin = hvs.HvsIndex.load(path)
+    assert len(twin) == n and twin.deleted_count() == 600 and twin.dtype == dtype
+    for a, b in zip(before, answers(twin)):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    twin.close()
+
+    assert idx.compact() == n - 600 and idx.deleted_count() == 0 and len(idx) == n - 600
+    for a, b in zip(before, answers(idx)):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)  # external ids moved with their rows
+    raw2, ids2, grp2, dl2 = idx.export()
+    np.testing.assert_array_equal(raw2, exp_raw[~dead])
+    np.testing.assert_array_equal(ids2, ext_ids[~dead])
+    np.testing.assert_array_equal(grp2, groups[~dead])
+    assert not dl2.any()
+    assert idx.compact() == n - 600  # nothing to do
+    # rows can be appended after a compaction, and positions restart from the compacted size
+    lo, hi = idx.add(rows[:10], ids=np.arange(10, dtype=np.int64), group_codes=groups[:10])
+    assert (lo, hi) == (n - 600, n - 590)
+    assert idx.compact(renumber_ids=True) == n - 590
+    np.testing.assert_array_equal(idx.export()[1], np.arange(n - 590))
+    idx.close()
+    empty = hvs.HvsIndex(d, dtype)
+    empty.save(path)
+    e2 = hvs.HvsIndex.load(path)
+    assert len(e2) == 0
+    e2.close()
+    empty.close()

@@ -29,6 +29,18 @@ def test_store_many_embeddings_gpu():
     s.close()
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32"), ("bf16", "bf16")])
+def test_store_compact_and_snapshot_gpu(tmp_path, vector_type, storage):
+    import hirag_prod_amd.store as st
+
+    async def load(directory):
+        return await st.HipVectorStore.load(directory, store_cases.make_embedding_func())
+
+    s = _store(vector_type)
+    store_cases.run(store_cases.scenario_compact_and_snapshot(s, load, storage, str(tmp_path / "snap")))
+    s.close()
+
+
 def test_small_kb_workload():
     """8192 chunks + 32768 triplets, D = 1536, halfvec, 3 query variants, workspace/kb filter,
     threshold 0.8: both scans of one user query (Chunks, Triplets) against the float64 oracle."""

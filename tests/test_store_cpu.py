@@ -23,6 +23,17 @@ def test_store_many_embeddings():
     store_cases.run(store_cases.scenario_many_embeddings(_store("halfvec"), "f16"))
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("bf16", "bf16")])
+def test_store_compact_and_snapshot(tmp_path, vector_type, storage):
+    import hirag_prod_amd.store as st
+
+    async def load(directory):
+        return await st.HipVectorStore.load(directory, store_cases.make_embedding_func(),
+                                            index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device))
+
+    store_cases.run(store_cases.scenario_compact_and_snapshot(_store(vector_type), load, storage, str(tmp_path / "snap")))
+
+
 def test_store_is_a_basevdb_and_refuses_without_gpu():
     import hirag_prod_amd as hvs
     import hirag_prod_amd.store as st
