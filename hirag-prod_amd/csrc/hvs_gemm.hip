@@ -45,7 +45,7 @@ struct SearchParams {
     int64_t T;      // corpus tiles in [row_begin, row_end)
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
     const uint32_t *remap;  // optional: X holds a compacted copy; remap[r] = row position of its row r in the index
-    int dbg;        // timing experiments only (HVS_DBG): 1 no DMA, 4 no barrier, 8 no epilogue
+    int dbg;        // timing experiments only (HVS_DBG): 4 no barrier, 8 no epilogue, 16 older block->XCD map
 };
 
 // One wave ranks the candidate array of one query, keeps the best `keep`, writes them in ascending
@@ -100,27 +100,37 @@ __device__ __forceinline__ float prefilter_bound(float tau, float q_inv) {
     return t - fabsf(t) * 4e-7f;
 }
 
-template <int DT, int FOLD>
-__global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
+template <int DT, int FOLD, class T>
+__global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int GT = T::GT, BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT, NW = T::NW;
     char *stages = smem;                                                      // 2 * STAGE_BYTES
     float *tau_lds = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);       // [BM] per folded query
     int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM] per folded query
     float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM] per A row
     float *bound_lds = qinv_lds + BM;                                         // [BM] per A row
-    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(bound_lds + BM);     // [4][CAND_MAX]
+    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(bound_lds + BM);     // [NW][CAND_MAX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / T::WN, wn = wave % T::WN;
     const int h = lane >> 5;
 
-    // block -> (query tile, corpus split); blocks that share a split sit on one XCD (b % 8) so that
-    // they stream the same corpus tiles through one L2
+    // block -> (query tile, corpus split).  Blocks are dealt to the 8 XCDs round-robin (b % 8); each XCD gets
+    // a rectangle of (QT / gq) query tiles x (S / gs) splits, gq = gcd(QT, 8), gs = 8 / gq, with as few
+    // query tiles as possible: their A slabs (re-read for every corpus tile) then stay in that XCD's L2,
+    // and only the corpus stream comes from HBM.
     int qt, s;
-    if ((p.S & 7) == 0) {
+    if ((p.S & 7) == 0 && !(p.dbg & 16)) {
+        const int gq = (p.QT & 7) == 0 ? 8 : ((p.QT & 3) == 0 ? 4 : ((p.QT & 1) == 0 ? 2 : 1));
+        const int gs = 8 / gq;
+        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int qn = p.QT / gq, sn = p.S / gs;
+        qt = (xcd % gq) * qn + t % qn;
+        s = (xcd / gq) * sn + t / qn;
+    } else if ((p.S & 7) == 0) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         qt = t % p.QT;
         s = xcd + 8 * (t / p.QT);
@@ -144,23 +154,23 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
         bound_lds[i] = prefilter_bound(p.thr, qi);
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
     zero_acc(acc);
     const int64_t n_tiles = tile_hi - tile_lo;
     const int64_t total_steps = n_tiles * p.nks;
-    TileSrc srcA, srcB;
+    TileSrcT<T::DMA_N> srcA, srcB;
     {
         const int64_t a_valid = p.nA - a_row0;
-        tile_src_init(srcA, p.A, a_row0, a_valid < BM ? (int)a_valid : BM, p.lda_bytes, tid);
+        tile_src_init<T>(srcA, p.A, a_row0, a_valid < BM ? (int)a_valid : BM, p.lda_bytes, tid);
     }
     auto init_b = [&](int64_t tile) {
         const int64_t r0 = p.row_begin + tile * BN;
         const int64_t valid = p.row_end - r0;
-        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld_bytes, tid);
+        tile_src_init<T>(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld_bytes, tid);
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles(srcA, srcB, stages, 0, wave);
+        dma_tiles<T>(srcA, srcB, stages, 0, wave);
     }
     __syncthreads();
 
@@ -168,25 +178,24 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
     int ks = 0;
     for (int64_t g = 0; g < total_steps; g++) {
         const int cur = (int)(g & 1);
-        // next step's coordinates
+        // next step's coordinates; after the last step the current tile's step 0 is fetched again (harmless,
+        // keeps the loop free of branches around the LDS-DMA instructions)
         int nks_next = ks + 1;
         int64_t ntile = tile;
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
-        const bool have_next = g + 1 < total_steps;
-        const bool prefetch = have_next && !(p.dbg & 1);
-        if (prefetch && nks_next == 0) init_b(ntile);
-        compute_step<DT>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, prefetch, srcA, srcB,
-                         stages + (cur ^ 1) * STAGE_BYTES, nks_next, wave);
+        if (nks_next == 0 && g + 1 < total_steps) init_b((p.dbg & 32) ? tile_lo : ntile);
+        compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
+                            nks_next, wave);
 
         if (ks == p.nks - 1) {
           if (!(p.dbg & 8)) {
             // ---- epilogue of tile `tile`: prefilter against the bound, exact test for survivors ----
-            const int64_t n_base = p.row_begin + tile * BN + wn * 64 + (lane & 31);
-            int64_t rows2[2];
-            bool ok2[2];
-            float invn2[2];
+            const int64_t n_base = p.row_begin + tile * BN + wn * (NT * 32) + (lane & 31);
+            int64_t rows2[NT];
+            bool ok2[NT];
+            float invn2[NT];
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NT; nt++) {
                 const int64_t row = n_base + nt * 32;
                 bool ok = row < p.row_end;
                 float invn = 0.0f;
@@ -201,13 +210,13 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
                 invn2[nt] = invn;
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
+            for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
-                    const int a_loc = wm * 64 + mt * 32 + 8 * gq + 4 * h;  // A row of register 4*gq (+0..3)
+                    const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;  // A row of register 4*gq (+0..3)
                     const f32x4 bnd = *reinterpret_cast<const f32x4 *>(bound_lds + a_loc);
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
+                    for (int nt = 0; nt < NT; nt++) {
                         bool any = false;
 #pragma unroll
                         for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[e];
@@ -254,9 +263,9 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
             const int trigger = eager < p.cap - BN ? eager : p.cap - BN;
             for (int base = 0; base < groups_per_tile; base += 64) {
                 const int ql = base + lane;
-                // wave w owns the queries with (index & 3) == w: a static split, so no wave's decision
+                // wave w owns the queries with index % NW == w: a static split, so no wave's decision
                 // depends on counters another wave is resetting at the same time
-                const bool need = ql < groups_per_tile && (ql & 3) == wave && cnt_lds[ql] > trigger;
+                const bool need = ql < groups_per_tile && (ql & (NW - 1)) == wave && cnt_lds[ql] > trigger;
                 uint64_t pending = __ballot(need);
                 while (pending) {
                     const int b = __ffsll((unsigned long long)pending) - 1;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 
     // ---- publish: every folded query's best k, ascending, padded ----
     __syncthreads();
-    for (int ql = wave; ql < groups_per_tile; ql += 4) {
+    for (int ql = wave; ql < groups_per_tile; ql += NW) {
         const int qo = q_out0 + ql;
         if (qo >= p.nq_out) break;
         int c = cnt_lds[ql];
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(GT, 2) void mfma_search_kernel(SearchParams p) {
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count);
 
-static size_t search_lds_bytes() { return (size_t)2 * STAGE_BYTES + BM * 16 + (size_t)4 * CAND_MAX * 8; }
+template <class T> static size_t search_lds_bytes() { return (size_t)2 * T::STAGE_BYTES + T::BM * 16 + (size_t)T::NW * CAND_MAX * 8; }
 
 static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
 
@@ -334,13 +343,14 @@ __global__ void build_a_kernel(const float *__restrict__ src, const float *__res
     if (threadIdx.x == 0) dst_inv[row] = src_inv[q * fold + sj];
 }
 
-template <int DT>
-static int launch_search(int pf, int grid, size_t lds, hipStream_t st, const SearchParams &p) {
+template <int DT, class T>
+static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p) {
+    const size_t lds = search_lds_bytes<T>();
 #define HVS_LAUNCH_SEARCH(F)                                                                                         \
     do {                                                                                                             \
-        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<DT, F>),                      \
+        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<DT, F, T>),                   \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-        mfma_search_kernel<DT, F><<<grid, GT, lds, st>>>(p);                                                         \
+        mfma_search_kernel<DT, F, T><<<grid, T::GT, lds, st>>>(p);                                                   \
     } while (0)
     if (pf == 1) HVS_LAUNCH_SEARCH(1);
     else if (pf == 2) HVS_LAUNCH_SEARCH(2);
@@ -390,7 +400,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // contract over a dense copy of them (tombstones alone are sparse and stay in the epilogue): the
     // contraction then costs n_live instead of n rows, and the copy is 2 * n_live * row bytes of traffic.
     const int64_t n_range = row_end - row_begin;
-    if ((group_filter >= 0 || d_mask) && n_range >= 4 * BN && row_end <= (int64_t)0xFFFFFFFFll && !getenv("HVS_NO_COMPACT")) {
+    if ((group_filter >= 0 || d_mask) && n_range >= 512 && row_end <= (int64_t)0xFFFFFFFFll && !getenv("HVS_NO_COMPACT")) {
         hvs_live_params lp{idx->groups, d_mask, p.deleted, group_filter, row_begin, row_end};
         uint32_t n_live = 0;
         HVS_TRY(hvs_live_count(idx, lp, &n_live));
@@ -422,14 +432,20 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
-    int cap = k + 2 * BN;
+    // tile shape: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
+    bool big = idx->dtype != HVS_F32 && nA > Tile128::BM;
+    if (const char *e = getenv("HVS_TILE")) big = idx->dtype != HVS_F32 && atoi(e) == 256;
+    const int bm = big ? Tile256::BM : Tile128::BM, bn = big ? Tile256::BN : Tile128::BN;
+    int cap = k + 2 * bn;
     cap = (cap + 63) / 64 * 64;
-    if (cap > CAND_MAX) cap = CAND_MAX;
+    if (cap > CAND_MAX) cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: one tile's survivors always fit
     p.cap = cap;
-    p.QT = (nA + BM - 1) / BM;
-    p.T = (row_end - row_begin + BN - 1) / BN;
-    // splits: fill the 2 blocks per CU, keep S a multiple of 8 (XCD affinity) and every split non-empty
-    int S = (512 + p.QT - 1) / p.QT;
+    p.QT = (nA + bm - 1) / bm;
+    p.T = (row_end - row_begin + bn - 1) / bn;
+    // splits: fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a
+    // multiple of 8 (XCD affinity) and every split non-empty
+    const int slots = big ? 256 : 512;
+    int S = (slots + p.QT - 1) / p.QT;
     S = (S + 7) / 8 * 8;
     if ((int64_t)S > p.T) S = (int)p.T;
     if (S >= 8) S = S / 8 * 8;
@@ -438,7 +454,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.dbg = 0;
     if (const char *e = getenv("HVS_DBG")) p.dbg = atoi(e);
     const int grid = p.QT * S;
-    const int groups_per_tile = BM / pf;
+    const int groups_per_tile = bm / pf;
 
     void *cand = nullptr, *bufA = nullptr, *bufB = nullptr;
     const size_t cand_bytes = (size_t)grid * groups_per_tile * cap * 8;
@@ -453,11 +469,12 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.partial = (uint64_t *)bufA;
     p.overflow = overflow;
 
-    const size_t lds = search_lds_bytes();
     HVS_TRY(hvs_prof_begin(idx));
-    if (idx->dtype == HVS_F32) HVS_TRY(launch_search<HVS_F32>(pf, grid, lds, idx->stream, p));
-    else if (idx->dtype == HVS_F16) HVS_TRY(launch_search<HVS_F16>(pf, grid, lds, idx->stream, p));
-    else HVS_TRY(launch_search<HVS_BF16>(pf, grid, lds, idx->stream, p));
+    if (idx->dtype == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, p)));
+    else if (idx->dtype == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, p)));
+    else if (idx->dtype == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, p)));
+    else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128>(pf, grid, idx->stream, p)));
+    else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, p)));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
     HVS_TRY(hvs_prof_begin(idx));
     HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count));

@@ -7,6 +7,8 @@
 // second kernel takes the minimum key over the centroid tiles.  No atomics, bit-reproducible.
 #include "hvs_gemm_tile.h"
 
+typedef Tile128 KT;  // block-tile shape of the assignment kernel
+
 struct AssignParams {
     const float *C;        // centroids [K, ldc] (padded copy, ldc a multiple of BK, pad columns zero)
     int ldc;
@@ -20,12 +22,12 @@ struct AssignParams {
     uint64_t *best;        // [CT, n] keys
 };
 
-__global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
+__global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stages = smem;
-    float *cn_lds = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);           // [BM]
-    uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + BM);                   // [2][64] keys (wm = 1 -> wm = 0)
+    float *cn_lds = reinterpret_cast<float *>(smem + 2 * KT::STAGE_BYTES);           // [KT::BM]
+    uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + KT::BM);                   // [2][64] keys (wm = 1 -> wm = 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -43,8 +45,8 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
         s = blockIdx.x / p.CT;
     }
     const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
-    const int64_t a_row0 = (int64_t)ct * BM;
-    for (int i = tid; i < BM; i += GT) {
+    const int64_t a_row0 = (int64_t)ct * KT::BM;
+    for (int i = tid; i < KT::BM; i += KT::GT) {
         const int64_t c = a_row0 + i;
         cn_lds[i] = c < p.K ? p.c_norm[c] : __builtin_inff();  // padding centroids never win
     }
@@ -55,12 +57,12 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
     TileSrc srcA, srcB;
     {
         const int64_t a_valid = p.K - a_row0;
-        tile_src_init(srcA, p.C, a_row0, a_valid < BM ? (int)a_valid : BM, p.ldc * 4, tid);
+        tile_src_init(srcA, p.C, a_row0, a_valid < KT::BM ? (int)a_valid : KT::BM, p.ldc * 4, tid);
     }
     auto init_b = [&](int64_t tile) {
-        const int64_t r0 = tile * BN;
+        const int64_t r0 = tile * KT::BN;
         const int64_t valid = p.n - r0;
-        tile_src_init(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld * 4, tid);
+        tile_src_init(srcB, p.X, r0, valid < KT::BN ? (int)valid : KT::BN, p.ld * 4, tid);
     };
     if (total_steps > 0) {
         init_b(tile_lo);
@@ -75,10 +77,9 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
         int ks_next = ks + 1;
         int64_t ntile = tile;
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
-        const bool have_next = g + 1 < total_steps;
-        if (have_next && ks_next == 0) init_b(ntile);
-        compute_step<HVS_F32>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, have_next, srcA, srcB,
-                              stages + (cur ^ 1) * STAGE_BYTES, ks_next, wave);
+        if (ks_next == 0 && g + 1 < total_steps) init_b(ntile);  // after the last step: re-fetch this tile's step 0 (unused)
+        compute_step<HVS_F32>(acc, stages + cur * KT::STAGE_BYTES, wm, wn, lane, srcA, srcB,
+                              stages + (cur ^ 1) * KT::STAGE_BYTES, ks_next, wave);
 
         uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
         const bool last = ks == p.nks - 1;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(GT, 2) void kmeans_assign_kernel(AssignParams p) {
             for (int nt = 0; nt < 2; nt++) {
                 const uint64_t o = xch[(wn * 2 + nt) * 32 + (lane & 31)];
                 const uint64_t b = o < bestk[nt] ? o : bestk[nt];
-                const int64_t row = tile * BN + wn * 64 + nt * 32 + (lane & 31);
+                const int64_t row = tile * KT::BN + wn * 64 + nt * 32 + (lane & 31);
                 if (row < p.n) p.best[(size_t)ct * p.n + row] = b;
             }
         }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__r
     }
 }
 
-static size_t assign_lds_bytes() { return (size_t)2 * STAGE_BYTES + BM * 4 + 2 * 64 * 8; }
+static size_t assign_lds_bytes() { return (size_t)2 * KT::STAGE_BYTES + KT::BM * 4 + 2 * 64 * 8; }
 
 extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids, int32_t *out_assign,
                                  float *out_sums, int64_t *out_counts, int on_device) {
@@ -228,8 +229,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     p.ld = ld;
     p.ldc = ldc;
     p.nks = ldc / 32;
-    p.CT = (K + BM - 1) / BM;
-    p.T = (n + BN - 1) / BN;
+    p.CT = (K + KT::BM - 1) / KT::BM;
+    p.T = (n + KT::BN - 1) / KT::BN;
     int S = (512 + p.CT - 1) / p.CT;
     S = (S + 7) / 8 * 8;
     if ((int64_t)S > p.T) S = (int)p.T;
@@ -258,7 +259,7 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     const size_t lds = assign_lds_bytes();
     HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HVS_TRY(hvs_prof_begin(idx));
-    kmeans_assign_kernel<<<p.CT * S, GT, lds, st>>>(p);
+    kmeans_assign_kernel<<<p.CT * S, KT::GT, lds, st>>>(p);
     HVS_HIP(hipGetLastError());
     int rg = (int)((n + 255) / 256);
     if (rg > 256 * 8) rg = 256 * 8;
