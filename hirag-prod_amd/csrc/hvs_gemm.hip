@@ -48,49 +48,82 @@ struct SearchParams {
     int dbg;        // timing experiments only (HVS_DBG): 4 no barrier, 8 no epilogue, 16 older block->XCD map
 };
 
-// One wave ranks the candidate array of one query, keeps the best `keep`, writes them in ascending
-// order to dst (dst == the array itself for an in-place compaction) and returns the new count.
-__device__ __forceinline__ int rank_select(const uint64_t *src, int cnt, int keep, uint64_t *dst, bool pad_dst,
-                                           volatile uint64_t *scratch, int lane, uint64_t *kth_key) {
-    uint64_t own[CAND_MAX / 64];
-    int rank[CAND_MAX / 64];
+// ---- candidate arrays: selection without sorting ------------------------------------------------
+// A wave holds a query's candidate array (up to CAND_MAX 64-bit keys, all distinct: the low word is the
+// row position) in registers, slot i = e * 64 + lane in own[e], unused slots = HVS_KEY_EMPTY.
+#define CAND_REGS (CAND_MAX / 64)
+
+__device__ __forceinline__ void cand_load(uint64_t (&own)[CAND_REGS], const uint64_t *arr, int cnt, int lane) {
 #pragma unroll
-    for (int e = 0; e < CAND_MAX / 64; e++) {
-        const int i = lane + 64 * e;
-        own[e] = i < cnt ? src[i] : HVS_KEY_EMPTY;
-        rank[e] = 0;
-        if (i < cnt) scratch[i] = own[e];
+    for (int e = 0; e < CAND_REGS; e++) {
+        const int i = e * 64 + lane;
+        own[e] = i < cnt ? arr[i] : HVS_KEY_EMPTY;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int j = 0; j < cnt; j++) {
-        const uint64_t kj = scratch[j];
+}
+
+// The k-th smallest key (k >= 1, at least k real keys present), found bit by bit from the top: the answer
+// is the smallest T with #{key <= T} >= k.  64 rounds of CAND_REGS compares + ballots, no data movement.
+__device__ __forceinline__ uint64_t cand_kth(const uint64_t (&own)[CAND_REGS], int k) {
+    uint64_t t = 0;
+    for (int bit = 63; bit >= 0; bit--) {
+        const uint64_t trial = t | ((1ull << bit) - 1ull);  // this bit 0, everything below it 1
+        int c = 0;
 #pragma unroll
-        for (int e = 0; e < CAND_MAX / 64; e++) rank[e] += (kj < own[e]) ? 1 : 0;
+        for (int e = 0; e < CAND_REGS; e++) c += __popcll(__ballot(own[e] <= trial));
+        if (c < k) t |= 1ull << bit;
     }
-    const int newcnt = cnt < keep ? cnt : keep;
-    uint64_t kth = HVS_KEY_EMPTY;
+    return t;
+}
+
+// Write the keys <= kth back to the front of arr (any order); returns how many there are.
+__device__ __forceinline__ int cand_keep(const uint64_t (&own)[CAND_REGS], uint64_t kth, uint64_t *arr, int lane) {
+    int base = 0;
 #pragma unroll
-    for (int e = 0; e < CAND_MAX / 64; e++) {
-        const int i = lane + 64 * e;
-        if (i < cnt && rank[e] < keep) {
-            dst[rank[e]] = own[e];
-            if (rank[e] == keep - 1) kth = own[e];
+    for (int e = 0; e < CAND_REGS; e++) {
+        const bool keep = own[e] <= kth;
+        const uint64_t m = __ballot(keep);
+        if (keep) arr[base + __popcll(m & ((1ull << lane) - 1ull))] = own[e];
+        base += __popcll(m);
+    }
+    return base;
+}
+
+// Ascending bitonic sort of 64 * KL keys held one slot per (register, lane), slot i = e * 64 + lane.
+__device__ __forceinline__ uint64_t sort_shfl_xor(uint64_t v, int mask) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <int KL> __device__ __forceinline__ void bitonic_sort(uint64_t (&a)[KL], int lane) {
+    constexpr int N = 64 * KL;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= 64) {  // partner slot is another register of the same lane
+                const int se = j >> 6;
+#pragma unroll
+                for (int e = 0; e < KL; e++) {
+                    if ((e & se) == 0) {
+                        const bool up = k >= N || ((e & (k >> 6)) == 0);
+                        const uint64_t x = a[e], y = a[e + se];
+                        const bool sw = up ? (y < x) : (x < y);
+                        a[e] = sw ? y : x;
+                        a[e + se] = sw ? x : y;
+                    }
+                }
+            } else {  // partner slot is the same register of lane ^ j
+#pragma unroll
+                for (int e = 0; e < KL; e++) {
+                    const bool up = k >= N ? true : (k >= 64 ? ((e & (k >> 6)) == 0) : ((lane & k) == 0));
+                    const bool lower = (lane & j) == 0;
+                    const uint64_t o = sort_shfl_xor(a[e], j);
+                    const uint64_t mn = a[e] < o ? a[e] : o, mx = a[e] < o ? o : a[e];
+                    a[e] = (lower == up) ? mn : mx;
+                }
+            }
         }
     }
-    if (pad_dst)
-        for (int i = newcnt + lane; i < keep; i += 64) dst[i] = HVS_KEY_EMPTY;
-    // broadcast the k-th key (held by exactly one lane, if any)
-    const uint64_t has = __ballot(kth != HVS_KEY_EMPTY);
-    if (has) {
-        const int src_lane = __ffsll((unsigned long long)has) - 1;
-        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)kth, src_lane);
-        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(kth >> 32), src_lane);
-        *kth_key = ((uint64_t)hi << 32) | lo;
-    } else {
-        *kth_key = HVS_KEY_EMPTY;
-    }
-    return newcnt;
 }
 
 // Lower bound on dot * inv_row that a row needs for its distance to be below tau, loosened so that
@@ -100,29 +133,20 @@ __device__ __forceinline__ float prefilter_bound(float tau, float q_inv) {
     return t - fabsf(t) * 4e-7f;
 }
 
-template <int DT, int FOLD, class T>
-__global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int GT = T::GT, BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT, NW = T::NW;
-    char *stages = smem;                                                      // 2 * STAGE_BYTES
-    float *tau_lds = reinterpret_cast<float *>(smem + 2 * STAGE_BYTES);       // [BM] per folded query
-    int *cnt_lds = reinterpret_cast<int *>(tau_lds + BM);                     // [BM] per folded query
-    float *qinv_lds = reinterpret_cast<float *>(cnt_lds + BM);                // [BM] per A row
-    float *bound_lds = qinv_lds + BM;                                         // [BM] per A row
-    uint64_t *scratch_all = reinterpret_cast<uint64_t *>(bound_lds + BM);     // [NW][CAND_MAX]
+// Per-block LDS state of a search kernel.
+struct BlockState {
+    float *tau;                  // [BM / FOLD] admission bound per folded query (strict <)
+    int *cnt;                    // [BM / FOLD] entries in the query's candidate array
+    float *qinv;                 // [BM] 1/|q| per A row
+    float *bound;                // [BM] prefilter bound per A row
+    uint64_t *my_cand;           // this block's candidate arrays [BM / FOLD][cap] (global memory)
+};
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / T::WN, wn = wave % T::WN;
-    const int h = lane >> 5;
-
-    // block -> (query tile, corpus split).  Blocks are dealt to the 8 XCDs round-robin (b % 8); each XCD gets
-    // a rectangle of (QT / gq) query tiles x (S / gs) splits, gq = gcd(QT, 8), gs = 8 / gq, with as few
-    // query tiles as possible: their A slabs (re-read for every corpus tile) then stay in that XCD's L2,
-    // and only the corpus stream comes from HBM.
-    int qt, s;
+// block -> (query tile, corpus split).  Blocks are dealt to the 8 XCDs round-robin (b % 8); each XCD gets
+// a rectangle of (QT / gq) query tiles x (S / gs) splits, gq = gcd(QT, 8), gs = 8 / gq, with as few
+// query tiles as possible: their A slabs (re-read for every corpus tile) then stay in that XCD's L2,
+// and only the corpus stream comes from HBM.
+__device__ __forceinline__ void block_coords(const SearchParams &p, int &qt, int &s) {
     if ((p.S & 7) == 0 && !(p.dbg & 16)) {
         const int gq = (p.QT & 7) == 0 ? 8 : ((p.QT & 3) == 0 ? 4 : ((p.QT & 1) == 0 ? 2 : 1));
         const int gs = 8 / gq;
@@ -138,21 +162,187 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
         qt = blockIdx.x % p.QT;
         s = blockIdx.x / p.QT;
     }
-    const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
-    const int64_t a_row0 = (int64_t)qt * BM;
-    constexpr int groups_per_tile = BM / FOLD;           // folded queries per tile
-    const int q_out0 = qt * groups_per_tile;             // first folded query of this tile
-    uint64_t *my_cand = p.cand + (size_t)blockIdx.x * groups_per_tile * p.cap;
-    volatile uint64_t *scratch = scratch_all + (size_t)wave * CAND_MAX;
+}
 
-    for (int i = tid; i < BM; i += GT) {
-        tau_lds[i] = p.thr;
-        cnt_lds[i] = 0;
+template <class T> __device__ __forceinline__ void block_state_init(const SearchParams &p, const BlockState &b, int64_t a_row0, int tid) {
+    for (int i = tid; i < T::BM; i += T::GT) {
+        b.tau[i] = p.thr;
+        b.cnt[i] = 0;
         const int64_t ar = a_row0 + i;
         const float qi = ar < p.nA ? p.q_inv[ar] : 0.0f;
-        qinv_lds[i] = qi;
-        bound_lds[i] = prefilter_bound(p.thr, qi);
+        b.qinv[i] = qi;
+        b.bound[i] = prefilter_bound(p.thr, qi);
     }
+}
+
+// Epilogue of one block tile: prefilter every score against its query's bound, exact test for the
+// survivors, append to the query's candidate array.
+template <int FOLD, class T>
+__device__ __forceinline__ void tile_epilogue(const SearchParams &p, const BlockState &b, f32x16 (&acc)[T::MT][T::NT], int64_t tile,
+                                              int wm, int wn, int lane) {
+    constexpr int MT = T::MT, NT = T::NT;
+    const int h = lane >> 5;
+    const int64_t n_base = p.row_begin + tile * T::BN + wn * (NT * 32) + (lane & 31);
+    int64_t rows2[NT];
+    bool ok2[NT];
+    float invn2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int64_t row = n_base + nt * 32;
+        bool ok = row < p.row_end;
+        float invn = 0.0f;
+        if (ok) {
+            invn = p.inv_norm[row];
+            if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+            if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+            if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+        }
+        rows2[nt] = row;
+        ok2[nt] = ok;
+        invn2[nt] = invn;
+    }
+    // opaque to the optimiser: otherwise every per-group address below is hoisted out of the caller's tile loop
+    // and kept in registers (or scratch) across the whole MFMA loop
+    int a_base = wm * (MT * 32) + 4 * h;
+    asm volatile("" : "+v"(a_base));
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const int a_loc = a_base + mt * 32 + 8 * gq;  // A row of register 4*gq (+0..3)
+            const f32x4 bnd = *reinterpret_cast<const f32x4 *>(b.bound + a_loc);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[e];
+                any &= ok2[nt];
+                if (__ballot(any)) {  // wave-uniform and rare once tau has tightened
+                    int av = a_loc;
+                    asm volatile("" : "+v"(av));  // keep this branch's address arithmetic inside it
+                    const f32x4 qi = *reinterpret_cast<const f32x4 *>(b.qinv + av);
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[e] = hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]);
+                    if (FOLD == 2) {
+                        d[0] = fminf(d[0], d[1]);
+                        d[2] = fminf(d[2], d[3]);
+                    } else if (FOLD == 4) {
+                        d[0] = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e += FOLD) {
+                        const int qv = (av + e) / FOLD;  // folded query, local to the tile
+                        if (any && d[e] < b.tau[qv]) {
+                            const int pos = atomicAdd(&b.cnt[qv], 1);
+                            if (pos < p.cap) {
+                                const uint32_t rp = p.remap ? p.remap[rows2[nt]] : (uint32_t)rows2[nt];
+                                b.my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), rp);
+                            }
+                            else *p.overflow = 1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Compaction after a tile's epilogue (and a block barrier): arrays that could overflow during the next
+// tile, and arrays that have grown enough for a fresher tau to pay (a stale tau admits ~count/k times too
+// many survivors).  Wave w owns the queries with index % NW == w: a static split, so no wave's decision
+// depends on counters another wave is resetting at the same time.
+template <int FOLD, class T>
+__device__ __forceinline__ void compact_lists(const SearchParams &p, const BlockState &b, int wave, int lane) {
+    constexpr int groups_per_tile = T::BM / FOLD;
+    const int eager = p.k * 2 > 32 ? p.k * 2 : 32;
+    const int trigger = eager < p.cap - T::BN ? eager : p.cap - T::BN;
+    for (int base = 0; base < groups_per_tile; base += 64) {
+        const int ql = base + lane;
+        const bool need = ql < groups_per_tile && (ql & (T::NW - 1)) == wave && b.cnt[ql] > trigger;
+        uint64_t pending = __ballot(need);
+        while (pending) {
+            const int bit = __ffsll((unsigned long long)pending) - 1;
+            pending &= pending - 1;
+            const int q = base + bit;
+            int c = b.cnt[q];
+            c = c > p.cap ? p.cap : c;
+            if (c <= p.k) continue;  // (cannot happen: trigger >= k)
+            uint64_t *arr = b.my_cand + (size_t)q * p.cap;
+            uint64_t own[CAND_REGS];
+            cand_load(own, arr, c, lane);
+            const uint64_t kth = cand_kth(own, p.k);
+            const int nc = cand_keep(own, kth, arr, lane);  // == k: keys are distinct
+            const float tau = hvs_unord((uint32_t)(kth >> 32));
+            if (lane == 0) {
+                b.cnt[q] = nc;
+                b.tau[q] = tau;
+            }
+            if (lane < FOLD) b.bound[q * FOLD + lane] = prefilter_bound(tau, b.qinv[q * FOLD + lane]);
+        }
+    }
+}
+
+// Every folded query's best k, ascending, padded, to partial[query][split][k].
+template <int FOLD, class T>
+__device__ __forceinline__ void publish_lists(const SearchParams &p, const BlockState &b, int q_out0, int s, int wave, int lane) {
+    constexpr int groups_per_tile = T::BM / FOLD;
+    for (int ql = wave; ql < groups_per_tile; ql += T::NW) {
+        const int qo = q_out0 + ql;
+        if (qo >= p.nq_out) break;
+        int c = b.cnt[ql];
+        c = c > p.cap ? p.cap : c;
+        uint64_t *arr = b.my_cand + (size_t)ql * p.cap;
+        if (c > p.k) {  // keep the k smallest (unordered), through the array itself
+            uint64_t own[CAND_REGS];
+            cand_load(own, arr, c, lane);
+            c = cand_keep(own, cand_kth(own, p.k), arr, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wave's stores before its reloads below
+        }
+        constexpr int KL = MFMA_MAX_K / 64;
+        uint64_t a[KL];
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const int i = e * 64 + lane;
+            a[e] = i < c ? arr[i] : HVS_KEY_EMPTY;
+        }
+        bitonic_sort<KL>(a, lane);
+        uint64_t *dst = p.partial + ((size_t)qo * p.S + s) * p.k;
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const int i = e * 64 + lane;
+            if (i < p.k) dst[i] = a[e];  // ascending, HVS_KEY_EMPTY padding sorts last
+        }
+    }
+}
+
+// LDS layout: [2 stages][tau][cnt][qinv][bound]
+template <class T> __device__ __forceinline__ BlockState block_state(char *smem, const SearchParams &p, int fold) {
+    BlockState b;
+    b.tau = reinterpret_cast<float *>(smem + 2 * T::STAGE_BYTES);
+    b.cnt = reinterpret_cast<int *>(b.tau + T::BM);
+    b.qinv = reinterpret_cast<float *>(b.cnt + T::BM);
+    b.bound = b.qinv + T::BM;
+    b.my_cand = p.cand + (size_t)blockIdx.x * (T::BM / fold) * p.cap;
+    return b;
+}
+
+template <int DT, int FOLD, class T>
+__global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT;
+    char *stages = smem;  // 2 * STAGE_BYTES
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / T::WN, wn = wave % T::WN;
+    int qt, s;
+    block_coords(p, qt, s);
+    const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
+    const int64_t a_row0 = (int64_t)qt * BM;
+    const BlockState b = block_state<T>(smem, p, FOLD);
+    block_state_init<T>(p, b, a_row0, tid);
 
     f32x16 acc[MT][NT];
     zero_acc(acc);
@@ -183,107 +373,16 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
         int nks_next = ks + 1;
         int64_t ntile = tile;
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
-        if (nks_next == 0 && g + 1 < total_steps) init_b((p.dbg & 32) ? tile_lo : ntile);
+        if (nks_next == 0 && g + 1 < total_steps) init_b(ntile);
         compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
                             nks_next, wave);
-
         if (ks == p.nks - 1) {
-          if (!(p.dbg & 8)) {
-            // ---- epilogue of tile `tile`: prefilter against the bound, exact test for survivors ----
-            const int64_t n_base = p.row_begin + tile * BN + wn * (NT * 32) + (lane & 31);
-            int64_t rows2[NT];
-            bool ok2[NT];
-            float invn2[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                const int64_t row = n_base + nt * 32;
-                bool ok = row < p.row_end;
-                float invn = 0.0f;
-                if (ok) {
-                    invn = p.inv_norm[row];
-                    if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
-                    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
-                    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
-                }
-                rows2[nt] = row;
-                ok2[nt] = ok;
-                invn2[nt] = invn;
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;  // A row of register 4*gq (+0..3)
-                    const f32x4 bnd = *reinterpret_cast<const f32x4 *>(bound_lds + a_loc);
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        bool any = false;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[e];
-                        any &= ok2[nt];
-                        if (__ballot(any)) {  // wave-uniform and rare once tau has tightened
-                            int av = a_loc;
-                            asm volatile("" : "+v"(av));  // keep this branch's address arithmetic inside it
-                            const f32x4 qi = *reinterpret_cast<const f32x4 *>(qinv_lds + av);
-                            float d[4];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) d[e] = hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]);
-                            if (FOLD == 2) {
-                                d[0] = fminf(d[0], d[1]);
-                                d[2] = fminf(d[2], d[3]);
-                            } else if (FOLD == 4) {
-                                d[0] = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; e += FOLD) {
-                                const int qv = (av + e) / FOLD;  // folded query, local to the tile
-                                if (any && d[e] < tau_lds[qv]) {
-                                    const int pos = atomicAdd(&cnt_lds[qv], 1);
-                                    if (pos < p.cap) {
-                                        const uint32_t rp = p.remap ? p.remap[rows2[nt]] : (uint32_t)rows2[nt];
-                                        my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), rp);
-                                    }
-                                    else *p.overflow = 1;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-          }
+            if (!(p.dbg & 8)) tile_epilogue<FOLD, T>(p, b, acc, tile, wm, wn, lane);
             zero_acc(acc);
         }
-
         if (!(p.dbg & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
-
         if (ks == p.nks - 1) {
-            // ---- compaction: arrays that could overflow during the next tile, and arrays that have grown
-            // enough for a fresher tau to pay (a stale tau admits ~count/k times too many survivors) ----
-            const int eager = p.k * 2 > 32 ? p.k * 2 : 32;
-            const int trigger = eager < p.cap - BN ? eager : p.cap - BN;
-            for (int base = 0; base < groups_per_tile; base += 64) {
-                const int ql = base + lane;
-                // wave w owns the queries with index % NW == w: a static split, so no wave's decision
-                // depends on counters another wave is resetting at the same time
-                const bool need = ql < groups_per_tile && (ql & (NW - 1)) == wave && cnt_lds[ql] > trigger;
-                uint64_t pending = __ballot(need);
-                while (pending) {
-                    const int b = __ffsll((unsigned long long)pending) - 1;
-                    pending &= pending - 1;
-                    const int q = base + b;
-                    int c = cnt_lds[q];
-                    c = c > p.cap ? p.cap : c;
-                    uint64_t kth;
-                    uint64_t *arr = my_cand + (size_t)q * p.cap;
-                    const int nc = rank_select(arr, c, p.k, arr, false, scratch, lane, &kth);
-                    if (lane == 0) cnt_lds[q] = nc;
-                    if (nc == p.k) {
-                        const float tau = hvs_unord((uint32_t)(kth >> 32));
-                        if (lane == 0) tau_lds[q] = tau;
-                        if (lane < FOLD) bound_lds[q * FOLD + lane] = prefilter_bound(tau, qinv_lds[q * FOLD + lane]);
-                    }
-                }
-            }
+            compact_lists<FOLD, T>(p, b, wave, lane);
             // the next epilogue is a whole K loop (>= 1 barrier) away, so no extra barrier is needed
             // unless the K loop has a single step
             if (p.nks == 1) __syncthreads();
@@ -291,17 +390,8 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
         ks = nks_next;
         tile = ntile;
     }
-
-    // ---- publish: every folded query's best k, ascending, padded ----
     __syncthreads();
-    for (int ql = wave; ql < groups_per_tile; ql += NW) {
-        const int qo = q_out0 + ql;
-        if (qo >= p.nq_out) break;
-        int c = cnt_lds[ql];
-        c = c > p.cap ? p.cap : c;
-        uint64_t kth;
-        rank_select(my_cand + (size_t)ql * p.cap, c, p.k, p.partial + ((size_t)qo * p.S + s) * p.k, true, scratch, lane, &kth);
-    }
+    publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
 #endif
 }
 
@@ -313,7 +403,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count);
 
-template <class T> static size_t search_lds_bytes() { return (size_t)2 * T::STAGE_BYTES + T::BM * 16 + (size_t)T::NW * CAND_MAX * 8; }
+template <class T> static size_t search_lds_bytes() { return (size_t)2 * T::STAGE_BYTES + T::BM * 16; }
 
 static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
 
@@ -436,9 +526,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     bool big = idx->dtype != HVS_F32 && nA > Tile128::BM;
     if (const char *e = getenv("HVS_TILE")) big = idx->dtype != HVS_F32 && atoi(e) == 256;
     const int bm = big ? Tile256::BM : Tile128::BM, bn = big ? Tile256::BN : Tile128::BN;
-    int cap = k + 2 * bn;
-    cap = (cap + 63) / 64 * 64;
-    if (cap > CAND_MAX) cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: one tile's survivors always fit
+    const int cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: the survivors of one more tile always fit
     p.cap = cap;
     p.QT = (nA + bm - 1) / bm;
     p.T = (row_end - row_begin + bn - 1) / bn;

@@ -7,7 +7,7 @@
 #include "hvs_internal.h"
 
 #define KB 128        // bytes of one tile row per k-step
-#define CAND_MAX 384  // capacity of a candidate array (entries), also the per-wave ranking scratch
+#define CAND_MAX 512  // capacity of a candidate array (entries): 8 keys per lane when a wave holds one in registers
 #define MFMA_MAX_K 128
 
 // Block-tile shapes.  BM x BN outputs per block, WM x WN waves, each wave (BM / WM) x (BN / WN) as
