@@ -44,48 +44,91 @@ struct SearchParams {
     int QT, S;
     int64_t T;      // corpus tiles in [row_begin, row_end)
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
+    unsigned long long *prof;  // timing experiments only: per-phase cycle sums of wave 0 lanes (HVS_DBG & 512)
     const uint32_t *remap;  // optional: X holds a compacted copy; remap[r] = row position of its row r in the index
-    int dbg;        // timing experiments only (HVS_DBG): 4 no barrier, 8 no epilogue, 16 older block->XCD map
+    int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
+                    // 512 per-phase cycle counts printed to stderr
 };
 
 // ---- candidate arrays: selection without sorting ------------------------------------------------
-// A wave holds a query's candidate array (up to CAND_MAX 64-bit keys, all distinct: the low word is the
-// row position) in registers, slot i = e * 64 + lane in own[e], unused slots = HVS_KEY_EMPTY.
-#define CAND_REGS (CAND_MAX / 64)
-
-__device__ __forceinline__ void cand_load(uint64_t (&own)[CAND_REGS], const uint64_t *arr, int cnt, int lane) {
+// A wave holds a query's candidate array (up to 64 R 64-bit keys, all distinct: the low word is the row
+// position) in registers, slot i = e * 64 + lane in own[e], unused slots = HVS_KEY_EMPTY.
+template <int R> __device__ __forceinline__ void cand_load(uint64_t (&own)[R], const uint64_t *arr, int cnt, int lane) {
 #pragma unroll
-    for (int e = 0; e < CAND_REGS; e++) {
+    for (int e = 0; e < R; e++) {
         const int i = e * 64 + lane;
         own[e] = i < cnt ? arr[i] : HVS_KEY_EMPTY;
     }
 }
 
 // The k-th smallest key (k >= 1, at least k real keys present), found bit by bit from the top: the answer
-// is the smallest T with #{key <= T} >= k.  64 rounds of CAND_REGS compares + ballots, no data movement.
-__device__ __forceinline__ uint64_t cand_kth(const uint64_t (&own)[CAND_REGS], int k) {
-    uint64_t t = 0;
-    for (int bit = 63; bit >= 0; bit--) {
-        const uint64_t trial = t | ((1ull << bit) - 1ull);  // this bit 0, everything below it 1
+// is the smallest T with #{key <= T} >= k.  First the 32 distance bits; if exactly one key carries the
+// k-th distance that key is the answer, otherwise (ties at the k-th distance) the 32 row bits follow.
+// Rounds of R compares + ballots, no data movement.
+template <int R> __device__ __forceinline__ uint64_t cand_kth(const uint64_t (&own)[R], int k) {
+    uint32_t hi[R];
+#pragma unroll
+    for (int e = 0; e < R; e++) hi[e] = (uint32_t)(own[e] >> 32);
+    uint32_t t = 0;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t trial = t | ((1u << bit) - 1u);  // this bit 0, everything below it 1
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < CAND_REGS; e++) c += __popcll(__ballot(own[e] <= trial));
-        if (c < k) t |= 1ull << bit;
+        for (int e = 0; e < R; e++) c += __popcll(__ballot(hi[e] <= trial));
+        if (c < k) t |= 1u << bit;
     }
-    return t;
+    // t = the k-th smallest distance image
+    int ties = 0;
+    uint64_t at = 0;  // the largest key carrying distance t
+#pragma unroll
+    for (int e = 0; e < R; e++) {
+        const uint64_t m = __ballot(hi[e] == t);
+        ties += __popcll(m);
+        if (m) {
+            const int src = 63 - __builtin_clzll((unsigned long long)m);  // within a register, higher lanes hold later slots -- any tie will do when it is alone
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)own[e], src);
+            at = ((uint64_t)t << 32) | lo;
+        }
+    }
+    if (ties == 1) return at;
+    uint64_t full = (uint64_t)t << 32;
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint64_t trial = full | ((1ull << bit) - 1ull);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < R; e++) c += __popcll(__ballot(own[e] <= trial));
+        if (c < k) full |= 1ull << bit;
+    }
+    return full;
 }
 
 // Write the keys <= kth back to the front of arr (any order); returns how many there are.
-__device__ __forceinline__ int cand_keep(const uint64_t (&own)[CAND_REGS], uint64_t kth, uint64_t *arr, int lane) {
+template <int R> __device__ __forceinline__ int cand_keep(const uint64_t (&own)[R], uint64_t kth, uint64_t *arr, int lane) {
     int base = 0;
 #pragma unroll
-    for (int e = 0; e < CAND_REGS; e++) {
+    for (int e = 0; e < R; e++) {
         const bool keep = own[e] <= kth;
         const uint64_t m = __ballot(keep);
         if (keep) arr[base + __popcll(m & ((1ull << lane) - 1ull))] = own[e];
         base += __popcll(m);
     }
     return base;
+}
+
+// Reduce arr[0, cnt) (cnt > k) to its k smallest keys, in place and unordered; returns the k-th smallest.
+template <int R> __device__ __forceinline__ uint64_t cand_reduce_r(uint64_t *arr, int cnt, int k, int lane) {
+    uint64_t own[R];
+    cand_load<R>(own, arr, cnt, lane);
+    const uint64_t kth = cand_kth<R>(own, k);
+    cand_keep<R>(own, kth, arr, lane);
+    return kth;
+}
+__device__ __forceinline__ uint64_t cand_reduce(uint64_t *arr, int cnt, int k, int lane) {
+    // registers for the occupied part of the array only: most compactions see one or two hundred keys
+    if (cnt <= 64) return cand_reduce_r<1>(arr, cnt, k, lane);
+    if (cnt <= 128) return cand_reduce_r<2>(arr, cnt, k, lane);
+    if (cnt <= 256) return cand_reduce_r<4>(arr, cnt, k, lane);
+    return cand_reduce_r<CAND_MAX / 64>(arr, cnt, k, lane);
 }
 
 // Ascending bitonic sort of 64 * KL keys held one slot per (register, lane), slot i = e * 64 + lane.
@@ -147,17 +190,13 @@ struct BlockState {
 // query tiles as possible: their A slabs (re-read for every corpus tile) then stay in that XCD's L2,
 // and only the corpus stream comes from HBM.
 __device__ __forceinline__ void block_coords(const SearchParams &p, int &qt, int &s) {
-    if ((p.S & 7) == 0 && !(p.dbg & 16)) {
+    if ((p.S & 7) == 0) {
         const int gq = (p.QT & 7) == 0 ? 8 : ((p.QT & 3) == 0 ? 4 : ((p.QT & 1) == 0 ? 2 : 1));
         const int gs = 8 / gq;
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         const int qn = p.QT / gq, sn = p.S / gs;
         qt = (xcd % gq) * qn + t % qn;
         s = (xcd / gq) * sn + t / qn;
-    } else if ((p.S & 7) == 0) {
-        const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
-        qt = t % p.QT;
-        s = xcd + 8 * (t / p.QT);
     } else {
         qt = blockIdx.x % p.QT;
         s = blockIdx.x / p.QT;
@@ -171,52 +210,73 @@ template <class T> __device__ __forceinline__ void block_state_init(const Search
         const int64_t ar = a_row0 + i;
         const float qi = ar < p.nA ? p.q_inv[ar] : 0.0f;
         b.qinv[i] = qi;
-        b.bound[i] = prefilter_bound(p.thr, qi);
+        b.bound[i] = ar < p.nA ? prefilter_bound(p.thr, qi) : INFINITY;  // padding rows of the A tile never pass
+    }
+}
+
+// Per-lane row data of a block tile, fetched at the START of the tile's K loop so that the latency is long
+// gone when the epilogue needs it: 1/|row| of the lane's NT rows, or NaN for a row that is out of range or
+// filtered out (group code, bitmask, tombstone) -- a NaN fails every comparison of the epilogue.
+template <class T>
+__device__ __forceinline__ void load_row_meta(const SearchParams &p, int64_t tile, int wn, int lane, float (&invn2)[T::NT]) {
+    const int64_t n_base = p.row_begin + tile * T::BN + wn * (T::NT * 32) + (lane & 31);
+#pragma unroll
+    for (int nt = 0; nt < T::NT; nt++) {
+        const int64_t row = n_base + nt * 32;
+        float invn = __builtin_nanf("");
+        if (row < p.row_end) {
+            bool ok = true;
+            if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+            if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+            if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+            if (ok) invn = p.inv_norm[row];
+        }
+        invn2[nt] = invn;
     }
 }
 
 // Epilogue of one block tile: prefilter every score against its query's bound, exact test for the
 // survivors, append to the query's candidate array.
 template <int FOLD, class T>
-__device__ __forceinline__ void tile_epilogue(const SearchParams &p, const BlockState &b, f32x16 (&acc)[T::MT][T::NT], int64_t tile,
-                                              int wm, int wn, int lane) {
+__device__ __forceinline__ void tile_epilogue(const SearchParams &p, const BlockState &b, f32x16 (&acc)[T::MT][T::NT],
+                                              const float (&invn2)[T::NT], int64_t tile, int64_t tile_first, int wm, int wn,
+                                              int lane) {
     constexpr int MT = T::MT, NT = T::NT;
     const int h = lane >> 5;
     const int64_t n_base = p.row_begin + tile * T::BN + wn * (NT * 32) + (lane & 31);
-    int64_t rows2[NT];
-    bool ok2[NT];
-    float invn2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        const int64_t row = n_base + nt * 32;
-        bool ok = row < p.row_end;
-        float invn = 0.0f;
-        if (ok) {
-            invn = p.inv_norm[row];
-            if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
-            if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
-            if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
-        }
-        rows2[nt] = row;
-        ok2[nt] = ok;
-        invn2[nt] = invn;
-    }
     // opaque to the optimiser: otherwise every per-group address below is hoisted out of the caller's tile loop
     // and kept in registers (or scratch) across the whole MFMA loop
     int a_base = wm * (MT * 32) + 4 * h;
     asm volatile("" : "+v"(a_base));
+    // Two levels.  Level 1, per 32 x 32 MFMA tile: the largest of the lane's 16 scores against the smallest
+    // of the 16 bounds -- one v_max3 chain, one multiply, one compare per tile; it is used once the block has
+    // seen enough rows for most tiles to hold no survivor (about k / rows_seen of the scores survive).
+    // Level 2, per group of four scores (four adjacent queries): the test proper.
+    const bool level1 = (int64_t)p.k * 4096 < (tile - tile_first) * T::BN;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
+        f32x4 bnd[4];
 #pragma unroll
-        for (int gq = 0; gq < 4; gq++) {
-            const int a_loc = a_base + mt * 32 + 8 * gq;  // A row of register 4*gq (+0..3)
-            const f32x4 bnd = *reinterpret_cast<const f32x4 *>(b.bound + a_loc);
+        for (int gq = 0; gq < 4; gq++) bnd[gq] = *reinterpret_cast<const f32x4 *>(b.bound + a_base + mt * 32 + 8 * gq);
+        float bmin = INFINITY;
+        if (level1) {
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
+            for (int gq = 0; gq < 4; gq++) bmin = fminf(bmin, fminf(fminf(bnd[gq][0], bnd[gq][1]), fminf(bnd[gq][2], bnd[gq][3])));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            if (level1) {
+                float m = acc[mt][nt][0];
+#pragma unroll
+                for (int e = 1; e < 16; e++) m = fmaxf(m, acc[mt][nt][e]);
+                if (!__ballot(m * invn2[nt] > bmin)) continue;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int a_loc = a_base + mt * 32 + 8 * gq;  // A row of register 4*gq (+0..3)
                 bool any = false;
 #pragma unroll
-                for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[e];
-                any &= ok2[nt];
+                for (int e = 0; e < 4; e++) any |= acc[mt][nt][4 * gq + e] * invn2[nt] > bnd[gq][e];
                 if (__ballot(any)) {  // wave-uniform and rare once tau has tightened
                     int av = a_loc;
                     asm volatile("" : "+v"(av));  // keep this branch's address arithmetic inside it
@@ -236,7 +296,8 @@ __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const Block
                         if (any && d[e] < b.tau[qv]) {
                             const int pos = atomicAdd(&b.cnt[qv], 1);
                             if (pos < p.cap) {
-                                const uint32_t rp = p.remap ? p.remap[rows2[nt]] : (uint32_t)rows2[nt];
+                                const int64_t row = n_base + nt * 32;
+                                const uint32_t rp = p.remap ? p.remap[row] : (uint32_t)row;
                                 b.my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), rp);
                             }
                             else *p.overflow = 1;
@@ -269,10 +330,8 @@ __device__ __forceinline__ void compact_lists(const SearchParams &p, const Block
             c = c > p.cap ? p.cap : c;
             if (c <= p.k) continue;  // (cannot happen: trigger >= k)
             uint64_t *arr = b.my_cand + (size_t)q * p.cap;
-            uint64_t own[CAND_REGS];
-            cand_load(own, arr, c, lane);
-            const uint64_t kth = cand_kth(own, p.k);
-            const int nc = cand_keep(own, kth, arr, lane);  // == k: keys are distinct
+            const uint64_t kth = cand_reduce(arr, c, p.k, lane);
+            const int nc = p.k;  // keys are distinct, so exactly k are <= the k-th
             const float tau = hvs_unord((uint32_t)(kth >> 32));
             if (lane == 0) {
                 b.cnt[q] = nc;
@@ -294,9 +353,8 @@ __device__ __forceinline__ void publish_lists(const SearchParams &p, const Block
         c = c > p.cap ? p.cap : c;
         uint64_t *arr = b.my_cand + (size_t)ql * p.cap;
         if (c > p.k) {  // keep the k smallest (unordered), through the array itself
-            uint64_t own[CAND_REGS];
-            cand_load(own, arr, c, lane);
-            c = cand_keep(own, cand_kth(own, p.k), arr, lane);
+            cand_reduce(arr, c, p.k, lane);
+            c = p.k;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wave's stores before its reloads below
         }
         constexpr int KL = MFMA_MAX_K / 64;
@@ -345,6 +403,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
     block_state_init<T>(p, b, a_row0, tid);
 
     f32x16 acc[MT][NT];
+    float invn2[NT];
     zero_acc(acc);
     const int64_t n_tiles = tile_hi - tile_lo;
     const int64_t total_steps = n_tiles * p.nks;
@@ -366,6 +425,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
 
     int64_t tile = tile_lo;
     int ks = 0;
+    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (p.dbg & 512) ? clock64() : 0;
     for (int64_t g = 0; g < total_steps; g++) {
         const int cur = (int)(g & 1);
         // next step's coordinates; after the last step the current tile's step 0 is fetched again (harmless,
@@ -374,21 +434,42 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
         int64_t ntile = tile;
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
         if (nks_next == 0 && g + 1 < total_steps) init_b(ntile);
+        if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
         compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
                             nks_next, wave);
-        if (ks == p.nks - 1) {
-            if (!(p.dbg & 8)) tile_epilogue<FOLD, T>(p, b, acc, tile, wm, wn, lane);
+        const bool tile_end = ks == p.nks - 1;
+        const bool prof = tile_end && (p.dbg & 512);
+        unsigned long long c1 = 0, c2 = 0, c3 = 0;
+        if (prof) c1 = clock64();
+        if (tile_end) {
+            if (!(p.dbg & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
             zero_acc(acc);
         }
+        if (prof) c2 = clock64();
         if (!(p.dbg & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
-        if (ks == p.nks - 1) {
+        if (prof) c3 = clock64();
+        if (tile_end) {
             compact_lists<FOLD, T>(p, b, wave, lane);
+            if (prof) {
+                const unsigned long long c4 = clock64();
+                pr_loop += c1 - pr_last;
+                pr_epi += c2 - c1;
+                pr_bar += c3 - c2;
+                pr_cmp += c4 - c3;
+                pr_last = c4;
+            }
             // the next epilogue is a whole K loop (>= 1 barrier) away, so no extra barrier is needed
             // unless the K loop has a single step
             if (p.nks == 1) __syncthreads();
         }
         ks = nks_next;
         tile = ntile;
+    }
+    if ((p.dbg & 512) && lane == 0) {
+        atomicAdd(&p.prof[0], pr_loop);
+        atomicAdd(&p.prof[1], pr_epi);
+        atomicAdd(&p.prof[2], pr_bar);
+        atomicAdd(&p.prof[3], pr_cmp);
     }
     __syncthreads();
     publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
@@ -502,6 +583,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
             uint32_t *positions = (uint32_t *)cr;
             float *c_inv = (float *)((char *)cr + pos_bytes);
             char *c_rows = (char *)cr + 2 * pos_bytes;
+            HVS_HIP(hipMemsetAsync(c_rows + copy_bytes, 0, HVS_ROWS_SLACK, idx->stream));  // see hvs_index_reserve
             if (n_live > 0) {
                 HVS_TRY(hvs_live_write(idx, lp, positions));
                 HVS_TRY(hvs_live_gather(idx, positions, n_live, c_rows, c_inv));
@@ -549,10 +631,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const size_t part_bytes = (size_t)nq * S * k * 8;
     const int P2 = (S + 31) / 32;
     HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
-    HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 256, &bufB));
+    HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
     bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
     int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
-    HVS_HIP(hipMemsetAsync(overflow, 0, 4, idx->stream));
+    HVS_HIP(hipMemsetAsync(overflow, 0, 64, idx->stream));
+    p.prof = (unsigned long long *)(overflow + 4);
     p.cand = (uint64_t *)cand;
     p.partial = (uint64_t *)bufA;
     p.overflow = overflow;
@@ -570,6 +653,13 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     int h_overflow = 0;
     HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
     HVS_HIP(hipStreamSynchronize(idx->stream));
+    if (p.dbg & 512) {
+        unsigned long long h_prof[4] = {0, 0, 0, 0};
+        HVS_HIP(hipMemcpy(h_prof, p.prof, sizeof(h_prof), hipMemcpyDeviceToHost));
+        const double waves = (double)grid * (idx->dtype != HVS_F32 && big ? Tile256::NW : Tile128::NW);
+        fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f\n",
+                h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
+    }
     HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
     return 0;
 }

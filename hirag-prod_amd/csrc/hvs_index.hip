@@ -410,10 +410,14 @@ extern "C" int hvs_index_reserve(hvs_index *idx, int64_t capacity_rows) {
     HVS_HIP(hipSetDevice(idx->device));
     const size_t row_bytes = (size_t)idx->ld * idx->elem_size;
     {
+        // Rows beyond n and HVS_ROWS_SLACK bytes after the last one are kept zero: the MFMA kernels fetch whole
+        // 128-byte k-steps, so the last step of a row whose pitch is not a multiple of 128 bytes reads into the
+        // row after it (times a zero-padded query: harmless as long as what it reads is finite).
         char *np = nullptr;
-        HVS_HIP(hipMalloc((void **)&np, (size_t)capacity_rows * row_bytes));
+        HVS_HIP(hipMalloc((void **)&np, (size_t)capacity_rows * row_bytes + HVS_ROWS_SLACK));
         if (idx->rows && idx->n)
             HVS_HIP(hipMemcpyAsync(np, idx->rows, (size_t)idx->n * row_bytes, hipMemcpyDeviceToDevice, idx->stream));
+        HVS_HIP(hipMemsetAsync(np + (size_t)idx->n * row_bytes, 0, (size_t)(capacity_rows - idx->n) * row_bytes + HVS_ROWS_SLACK, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));
         if (idx->rows) HVS_HIP(hipFree(idx->rows));
         idx->rows = np;
@@ -628,10 +632,15 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
         int rc = 0;
         do {  // new arrays sized for the survivors; the old ones are released only when every copy has succeeded
             hipError_t e;
-            if ((e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4)) != hipSuccess || (e = hipMalloc((void **)&rows, (size_t)cap * pitch)) != hipSuccess ||
+            if ((e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4)) != hipSuccess || (e = hipMalloc((void **)&rows, (size_t)cap * pitch + HVS_ROWS_SLACK)) != hipSuccess ||
                 (e = hipMalloc((void **)&inv, (size_t)cap * 4)) != hipSuccess || (e = hipMalloc((void **)&ids, (size_t)cap * 8)) != hipSuccess ||
                 (e = hipMalloc((void **)&groups, (size_t)cap * 4)) != hipSuccess) {
                 hvs_set_error("hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
+                rc = 1;
+                break;
+            }
+            if ((e = hipMemsetAsync(rows + (size_t)n_live * pitch, 0, (size_t)(cap - n_live) * pitch + HVS_ROWS_SLACK, idx->stream)) != hipSuccess) {
+                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
                 rc = 1;
                 break;
             }

@@ -94,6 +94,8 @@ int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live);
 int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *positions);        // after hvs_live_count
 int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv);
 
+#define HVS_ROWS_SLACK 256  // zeroed bytes kept after the last row of a row matrix (see hvs_index_reserve)
+
 static inline int hvs_elem_size(int dtype) { return dtype == HVS_F32 ? 4 : 2; }
 
 // ---------------------------------------------------------------------------
