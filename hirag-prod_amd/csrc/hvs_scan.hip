@@ -133,6 +133,36 @@ __device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k
     (void)thr_key;
 }
 
+// ---- dot-product reduction across the lanes of a row group ----------------------------------------
+// Each lane holds V partial sums (V a power of two, V <= W) that must be added up over the W lanes of its
+// group.  V independent butterflies would cost V log2(W) shuffles; instead the first log2(V) steps halve
+// the number of sums a lane carries (it keeps one half and hands the other to its partner), the remaining
+// steps are plain butterflies on the one sum left: V - 1 + log2(W / V) shuffles.  Afterwards the total of
+// sum j sits in a[0] of every lane whose index inside the group, shifted right by log2(W / V), equals j.
+template <int V, int W> __device__ __forceinline__ void reduce_scatter(float (&a)[V], int l) {
+    int n = V;
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) {
+        if (n > 1) {
+            const int half = n / 2;
+            const bool upper = (l & o) != 0;
+#pragma unroll
+            for (int i = 0; i < V / 2; i++) {
+                if (i < half) {
+                    const float send = upper ? a[i] : a[i + half];
+                    const float keep = upper ? a[i + half] : a[i];
+                    a[i] = keep + __shfl_xor(send, o);
+                }
+            }
+            n = half;
+        } else {
+            a[0] += __shfl_xor(a[0], o);
+        }
+    }
+}
+constexpr int hvs_pow2_ceil(int v) { return v <= 1 ? 1 : 2 * hvs_pow2_ceil((v + 1) / 2); }
+constexpr int hvs_log2(int v) { return v <= 1 ? 0 : 1 + hvs_log2(v / 2); }
+
 // ---- the scan -----------------------------------------------------------------------------------
 // LPR = lanes per row: 64 (one row per wave pass) or 32 (two rows per pass, for rows of <= 2 KB, which
 // would otherwise leave half the lanes idle and pay the reduction and selection once per 1.5 KB).
@@ -257,38 +287,92 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 for (int r = 0; r < SCAN_R; r++) acc[r][q] = Chunk<DT>::dot(v[r], qv, acc[r][q]);
             }
         }
-        // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
-#pragma unroll
-        for (int r = 0; r < SCAN_R; r++)
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                float s = acc[r][q];
-#pragma unroll
-                for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                acc[r][q] = s;
+        if (NQ == 1) {
+            // One query: the tail below costs as much as the row stream hides, so it is kept short.
+            // add up the SCAN_R * NQ partial sums over the LPR lanes of the row group, then hand every lane of
+            // the group all the totals
+            constexpr int V = hvs_pow2_ceil(SCAN_R * NQ);
+            static_assert(V <= LPR, "more sums per lane than lanes per row group");
+            {
+                float a[V];
+    #pragma unroll
+                for (int i = 0; i < V; i++) a[i] = i < SCAN_R * NQ ? acc[i / NQ][i % NQ] : 0.0f;
+                reduce_scatter<V, LPR>(a, l);
+                constexpr int SH = hvs_log2(LPR / V);
+    #pragma unroll
+                for (int r = 0; r < SCAN_R; r++)
+    #pragma unroll
+                    for (int q = 0; q < NQ; q++) acc[r][q] = __shfl(a[0], sub * LPR + ((r * NQ + q) << SH));
             }
-#pragma unroll
-        for (int r = 0; r < SCAN_R; r++) {
-            const int64_t row = rowv[r];
-            const float inv = live[r] ? p.inv_norm[row] : 0.0f;
-            float dd[NQ];
-#pragma unroll
-            for (int t = 0; t < NQ; t++) dd[t] = hvs_cos_dist(acc[r][t], inv, qinv[t]);
-#pragma unroll
+            // distances (in place of the dot products): every lane computes them for all SCAN_R rows of its group
+    #pragma unroll
+            for (int r = 0; r < SCAN_R; r++)
+    #pragma unroll
+                for (int t = 0; t < NQ; t++) acc[r][t] = hvs_cos_dist(acc[r][t], live[r] ? p.inv_norm[rowv[r]] : 0.0f, qinv[t]);
+            // lane r of the group offers row r, so that one pass over the wave's list per query takes all RG rows
+            // of this iteration
+    #pragma unroll
             for (int qo = 0; qo < NQ; qo++) {
                 if (qo >= p.nq_out) break;
-                float d = __builtin_nanf("");
-#pragma unroll
-                for (int t = 0; t < NQ; t++) {
-                    const int j = t - qo * p.fold;  // wave-uniform
-                    if (j >= 0 && j < p.fold) d = fminf(d, dd[t]);  // fminf drops a NaN operand: LEAST semantics
+                float d = __builtin_nanf("");  // this lane's row (r = l), LEAST over the query's embeddings
+                int64_t row = 0;
+    #pragma unroll
+                for (int r = 0; r < SCAN_R; r++) {
+                    float dr = __builtin_nanf("");
+    #pragma unroll
+                    for (int t = 0; t < NQ; t++) {
+                        const int j = t - qo * p.fold;  // wave-uniform
+                        if (j >= 0 && j < p.fold) dr = fminf(dr, acc[r][t]);  // fminf drops a NaN operand: LEAST semantics
+                    }
+                    if (DISTONLY) {
+                        if (l == 0 && live[r]) p.dist_out[rowv[r] - p.row_begin] = dr;
+                    } else if (l == r && live[r]) {
+                        d = dr;
+                        row = rowv[r];
+                    }
                 }
-                if (DISTONLY) {
-                    if (l == 0 && live[r]) p.dist_out[row - p.row_begin] = d;
-                } else {
-                    // one lane per row offers the row's key; NaN distances and filtered rows offer nothing
-                    const uint64_t key = (l == 0 && live[r] && d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
+                if (!DISTONLY) {
+                    // NaN distances and filtered rows offer nothing
+                    const uint64_t key = d == d ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
                     wave_offer(myL + (size_t)qo * p.k, cnt[qo], p.k, tau[qo], thr_key, key, lane);
+                }
+            }
+        } else {
+            // Several embeddings: rows are finished one at a time, which keeps few values alive (registers
+            // decide the occupancy here).
+            // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
+    #pragma unroll
+            for (int r = 0; r < SCAN_R; r++)
+    #pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    float s = acc[r][q];
+    #pragma unroll
+                    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                    acc[r][q] = s;
+                }
+    #pragma unroll
+            for (int r = 0; r < SCAN_R; r++) {
+                const int64_t row = rowv[r];
+                const float inv = live[r] ? p.inv_norm[row] : 0.0f;
+                float dd[NQ];
+    #pragma unroll
+                for (int t = 0; t < NQ; t++) dd[t] = hvs_cos_dist(acc[r][t], inv, qinv[t]);
+    #pragma unroll
+                for (int qo = 0; qo < NQ; qo++) {
+                    if (qo >= p.nq_out) break;
+                    float d = __builtin_nanf("");
+    #pragma unroll
+                    for (int t = 0; t < NQ; t++) {
+                        const int j = t - qo * p.fold;  // wave-uniform
+                        if (j >= 0 && j < p.fold) d = fminf(d, dd[t]);  // fminf drops a NaN operand: LEAST semantics
+                    }
+                    if (DISTONLY) {
+                        if (l == 0 && live[r]) p.dist_out[row - p.row_begin] = d;
+                    } else {
+                        // one lane per row offers the row's key; NaN distances and filtered rows offer nothing
+                        const uint64_t key = (l == 0 && live[r] && d == d) ? hvs_make_key(hvs_ord(d), (uint32_t)row) : HVS_KEY_EMPTY;
+                        wave_offer(myL + (size_t)qo * p.k, cnt[qo], p.k, tau[qo], thr_key, key, lane);
+                    }
                 }
             }
         }
