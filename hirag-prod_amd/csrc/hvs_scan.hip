@@ -11,7 +11,10 @@
 
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
-#define SCAN_R 4          // rows a wave has in flight
+#define SCAN_R 4          // rows a wave has in flight (one or two embeddings)
+// With three or more embeddings the accumulators and the per-row tail grow; two rows in flight keep the
+// kernel at three waves per SIMD instead of two.
+constexpr int scan_rows_in_flight(int nq) { return nq >= 3 ? 2 : SCAN_R; }
 #define MERGE_FAN 32      // lists merged by one wave of the merge kernel
 
 struct ScanParams {
@@ -37,25 +40,34 @@ struct ScanParams {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- 16 bytes of a row against 16 bytes of a query (same element type, same k range) ----------
-// fp32: four fmaf.  fp16 / bf16: four v_dot2c_f32_{f16,bf16}: two exact products added to the fp32
+// fp32: two packed fmas (even / odd partial sums).  fp16 / bf16: four v_dot2c_f32_{f16,bf16}: two exact products added to the fp32
 // accumulator each; the query is held in the row's own 16-bit type, which loses nothing because it
 // has already been rounded to that type.
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 template <int DT> struct Chunk;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <> struct Chunk<HVS_F32> {
     static constexpr int ESZ = 4;
-    __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
-        acc = fmaf(__uint_as_float(v.x), __uint_as_float(q.x), acc);
-        acc = fmaf(__uint_as_float(v.y), __uint_as_float(q.y), acc);
-        acc = fmaf(__uint_as_float(v.z), __uint_as_float(q.z), acc);
-        return fmaf(__uint_as_float(v.w), __uint_as_float(q.w), acc);
+    // two partial sums per dot product (even and odd elements), so that 16 bytes cost two v_pk_fma_f32
+    // instead of four v_fma_f32: with several embeddings per row the scan is VALU-issue-limited
+    typedef f32x2 Acc;
+    __device__ static __forceinline__ Acc zero() { return (f32x2){0.0f, 0.0f}; }
+    __device__ static __forceinline__ Acc dot(const u32x4 &v, const u32x4 &q, Acc acc) {
+        const f32x2 v0 = {__uint_as_float(v.x), __uint_as_float(v.y)}, v1 = {__uint_as_float(v.z), __uint_as_float(v.w)};
+        const f32x2 q0 = {__uint_as_float(q.x), __uint_as_float(q.y)}, q1 = {__uint_as_float(q.z), __uint_as_float(q.w)};
+        acc = __builtin_elementwise_fma(v0, q0, acc);
+        return __builtin_elementwise_fma(v1, q1, acc);
     }
+    __device__ static __forceinline__ float finish(Acc acc) { return acc.x + acc.y; }
     __device__ static __forceinline__ void put_query(char *dst, int c, float v) { reinterpret_cast<float *>(dst)[c] = v; }
 };
 template <> struct Chunk<HVS_F16> {
     static constexpr int ESZ = 2;
+    typedef float Acc;
+    __device__ static __forceinline__ Acc zero() { return 0.0f; }
+    __device__ static __forceinline__ float finish(Acc acc) { return acc; }
     __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
         h16x2 a[4], b[4];
         __builtin_memcpy(a, &v, 16);
@@ -70,6 +82,9 @@ template <> struct Chunk<HVS_F16> {
 };
 template <> struct Chunk<HVS_BF16> {
     static constexpr int ESZ = 2;
+    typedef float Acc;
+    __device__ static __forceinline__ Acc zero() { return 0.0f; }
+    __device__ static __forceinline__ float finish(Acc acc) { return acc; }
     __device__ static __forceinline__ float dot(const u32x4 &v, const u32x4 &q, float acc) {
         bf16x2 a[4], b[4];
         __builtin_memcpy(a, &v, 16);
@@ -176,8 +191,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_bytes + 15) & ~(size_t)15));
     uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * 8]
 
+    constexpr int R = scan_rows_in_flight(NQ);
     constexpr int SUB = 64 / LPR;     // rows per wave pass
-    constexpr int RG = SCAN_R * SUB;  // rows per wave iteration
+    constexpr int RG = R * SUB;  // rows per wave iteration
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -253,10 +269,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             n_items = left >= 64 ? 64 : (int)left;
         }
       for (int it = 0; it < n_items; it++) {
-        int64_t rowv[SCAN_R];
-        bool live[SCAN_R];
+        int64_t rowv[R];
+        bool live[R];
 #pragma unroll
-        for (int r = 0; r < SCAN_R; r++) {
+        for (int r = 0; r < R; r++) {
             if (filtered) {
                 const int qi = it * RG + r * SUB + sub;
                 live[r] = qi < total;
@@ -266,17 +282,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 live[r] = rowv[r] < p.row_end;
             }
         }
-        float acc[SCAN_R][NQ];
+        typename Chunk<DT>::Acc part[R][NQ];
 #pragma unroll
-        for (int r = 0; r < SCAN_R; r++)
+        for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int q = 0; q < NQ; q++) acc[r][q] = 0.0f;
+            for (int q = 0; q < NQ; q++) part[r][q] = Chunk<DT>::zero();
 
 #pragma unroll 2
         for (int c = l; c < p.chunks; c += LPR) {
-            u32x4 v[SCAN_R];
+            u32x4 v[R];
 #pragma unroll
-            for (int r = 0; r < SCAN_R; r++) {
+            for (int r = 0; r < R; r++) {
                 v[r] = (u32x4){0u, 0u, 0u, 0u};
                 if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
             }
@@ -284,29 +300,34 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             for (int q = 0; q < NQ; q++) {
                 const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
 #pragma unroll
-                for (int r = 0; r < SCAN_R; r++) acc[r][q] = Chunk<DT>::dot(v[r], qv, acc[r][q]);
+                for (int r = 0; r < R; r++) part[r][q] = Chunk<DT>::dot(v[r], qv, part[r][q]);
             }
         }
+        float acc[R][NQ];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[r][q] = Chunk<DT>::finish(part[r][q]);
         if (NQ == 1) {
             // One query: the tail below costs as much as the row stream hides, so it is kept short.
-            // add up the SCAN_R * NQ partial sums over the LPR lanes of the row group, then hand every lane of
+            // add up the R * NQ partial sums over the LPR lanes of the row group, then hand every lane of
             // the group all the totals
-            constexpr int V = hvs_pow2_ceil(SCAN_R * NQ);
+            constexpr int V = hvs_pow2_ceil(R * NQ);
             static_assert(V <= LPR, "more sums per lane than lanes per row group");
             {
                 float a[V];
     #pragma unroll
-                for (int i = 0; i < V; i++) a[i] = i < SCAN_R * NQ ? acc[i / NQ][i % NQ] : 0.0f;
+                for (int i = 0; i < V; i++) a[i] = i < R * NQ ? acc[i / NQ][i % NQ] : 0.0f;
                 reduce_scatter<V, LPR>(a, l);
                 constexpr int SH = hvs_log2(LPR / V);
     #pragma unroll
-                for (int r = 0; r < SCAN_R; r++)
+                for (int r = 0; r < R; r++)
     #pragma unroll
                     for (int q = 0; q < NQ; q++) acc[r][q] = __shfl(a[0], sub * LPR + ((r * NQ + q) << SH));
             }
-            // distances (in place of the dot products): every lane computes them for all SCAN_R rows of its group
+            // distances (in place of the dot products): every lane computes them for all R rows of its group
     #pragma unroll
-            for (int r = 0; r < SCAN_R; r++)
+            for (int r = 0; r < R; r++)
     #pragma unroll
                 for (int t = 0; t < NQ; t++) acc[r][t] = hvs_cos_dist(acc[r][t], live[r] ? p.inv_norm[rowv[r]] : 0.0f, qinv[t]);
             // lane r of the group offers row r, so that one pass over the wave's list per query takes all RG rows
@@ -317,7 +338,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 float d = __builtin_nanf("");  // this lane's row (r = l), LEAST over the query's embeddings
                 int64_t row = 0;
     #pragma unroll
-                for (int r = 0; r < SCAN_R; r++) {
+                for (int r = 0; r < R; r++) {
                     float dr = __builtin_nanf("");
     #pragma unroll
                     for (int t = 0; t < NQ; t++) {
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             // decide the occupancy here).
             // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
     #pragma unroll
-            for (int r = 0; r < SCAN_R; r++)
+            for (int r = 0; r < R; r++)
     #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     float s = acc[r][q];
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                     acc[r][q] = s;
                 }
     #pragma unroll
-            for (int r = 0; r < SCAN_R; r++) {
+            for (int r = 0; r < R; r++) {
                 const int64_t row = rowv[r];
                 const float inv = live[r] ? p.inv_norm[row] : 0.0f;
                 float dd[NQ];
@@ -637,7 +658,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const int chunks = idx->ld * idx->elem_size / 16;
     const int lpr = scan_lpr(chunks);
     const int64_t n_rows = row_end - row_begin;
-    const int rows_per_iter = SCAN_R * (64 / lpr);
+    const int rows_per_iter = scan_rows_in_flight(NQ) * (64 / lpr);
     const int64_t row_groups = (n_rows + rows_per_iter - 1) / rows_per_iter;
     const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
     int grid = 0;
@@ -801,7 +822,7 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
     p.k = 1;
     p.group_filter = -1;
     p.dist_out = d_out;
-    const int64_t row_groups = (n_rows + SCAN_R - 1) / SCAN_R;
+    const int64_t row_groups = (n_rows + scan_rows_in_flight(NQ) - 1) / scan_rows_in_flight(NQ);
     const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
     int grid = 0;
     HVS_TRY(hvs_prof_begin(idx));
