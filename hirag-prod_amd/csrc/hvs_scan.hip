@@ -223,30 +223,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
 
-    // This wave owns row groups gwave, gwave + nwaves, ...  With a filter (group code, row mask,
-    // tombstones) the wave first evaluates the filter of 64 of its groups at once, one group per lane
-    // (one round trip for the dependent loads of the filter columns instead of one per group), packs
-    // the surviving row numbers into a small LDS queue, and then streams only those rows, RG at a time.
+    // Without a filter this wave owns row groups gwave, gwave + nwaves, ... (RG rows each).  With a filter
+    // (group code, row mask, tombstones) it owns whole spans of 64 * RG consecutive rows instead: lane i
+    // evaluates the filter of rows i, i + 64, ... of the span (consecutive lanes read consecutive filter
+    // words: one cache line per load instruction, not one per lane), a wave prefix sum packs the surviving
+    // row numbers into a small LDS queue, and only those rows are streamed, RG at a time.
     const bool filtered = !DISTONLY && (p.group_filter >= 0 || p.mask != nullptr || p.deleted != nullptr);
     const int64_t my_groups = n_groups > gwave ? (n_groups - gwave + nwaves - 1) / nwaves : 0;
+    const int64_t n_spans = (p.row_end - p.row_begin + 64 * RG - 1) / (64 * RG);
+    const int64_t n_outer = filtered ? (n_spans > gwave ? (n_spans - gwave + nwaves - 1) / nwaves : 0) : (my_groups + 63) / 64;
     volatile uint32_t *rowq = row_queue + wave * (64 * 8);
-    for (int64_t base = 0; base < my_groups; base += 64) {
+    for (int64_t ob = 0; ob < n_outer; ob++) {
+        const int64_t base = ob * 64;
         int n_items;
         int total = 0;
         if (filtered) {
             uint32_t mybits = 0;
-            const int64_t gi = base + lane;
-            const int64_t row0 = p.row_begin + (gwave + gi * nwaves) * RG;
-            if (gi < my_groups) {
+            const int64_t row0 = p.row_begin + (gwave + ob * nwaves) * (64 * RG) + lane;
 #pragma unroll
-                for (int i = 0; i < RG; i++) {
-                    const int64_t row = row0 + i;
-                    bool ok = row < p.row_end;
-                    if (ok && p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
-                    if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
-                    if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
-                    mybits |= (ok ? 1u : 0u) << i;
-                }
+            for (int i = 0; i < RG; i++) {
+                const int64_t row = row0 + i * 64;
+                bool ok = row < p.row_end;
+                if (ok && p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+                if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
+                if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+                mybits |= (ok ? 1u : 0u) << i;
             }
             // exclusive prefix sum of the live counts over the lanes
             const int mine = __popc(mybits);
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             wave_fence();  // earlier reads of the queue are done
 #pragma unroll
             for (int i = 0; i < RG; i++)
-                if ((mybits >> i) & 1u) rowq[pos++] = (uint32_t)(row0 + i);
+                if ((mybits >> i) & 1u) rowq[pos++] = (uint32_t)(row0 + i * 64);
             wave_fence();
             n_items = (total + RG - 1) / RG;
         } else {
