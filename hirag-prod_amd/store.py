@@ -60,6 +60,7 @@ class _Table:
         self.colset = set(self.columns)
         self.rows: List[Optional[dict]] = []  # position -> row (None = deleted)
         self.pk_map: Dict[tuple, int] = {}
+        self.key_index: Dict[str, Dict[Any, List[int]]] = {}
         self.index = None  # HvsIndex for embedded tables
         # filter columns as arrays, grown geometrically
         self.group = np.zeros(0, dtype=np.int32)
@@ -68,6 +69,44 @@ class _Table:
         self.uri_code = np.zeros(0, dtype=np.int32)
         self.private = np.zeros(0, dtype=bool)
         self.live = np.zeros(0, dtype=bool)
+
+    # -- secondary indexes on scalar columns (documentKey, uri, ...): value -> ascending row positions.
+    # Built on first use, kept current by note_insert / note_delete, dropped when positions change.
+    def positions_where(self, column: str, values) -> Optional[List[int]]:
+        """Live positions whose ``column`` is one of ``values``, ascending; None if the column holds
+        unhashable values (the caller then scans)."""
+        index = self.key_index.get(column)
+        if index is None:
+            index = {}
+            try:
+                for pos, row in enumerate(self.rows):
+                    if row is not None:
+                        index.setdefault(row.get(column), []).append(pos)
+            except TypeError:
+                return None
+            self.key_index[column] = index
+        hits: List[int] = []
+        try:
+            for v in values:
+                hits.extend(index.get(v, ()))
+        except TypeError:
+            return None
+        hits.sort()
+        return hits
+
+    def note_insert(self, pos: int, row: dict) -> None:
+        for column, index in list(self.key_index.items()):
+            try:
+                index.setdefault(row.get(column), []).append(pos)
+            except TypeError:
+                del self.key_index[column]
+
+    def note_delete(self, pos: int, row: dict) -> None:
+        for column, index in list(self.key_index.items()):
+            try:
+                index[row.get(column)].remove(pos)
+            except (KeyError, ValueError, TypeError):
+                del self.key_index[column]
 
     def _grow(self, n: int) -> None:
         if n <= len(self.group):
@@ -248,6 +287,7 @@ class HipVectorStore(BaseVDB):
                     stored.pop("vector", None)  # the vector lives in HBM
                     table.rows.append(stored)
                     table.pk_map[pk] = pos
+                    table.note_insert(pos, stored)
                 mat = np.stack(new_vecs)
                 lo, hi = await asyncio.to_thread(index.add, mat, None, groups)
                 assert lo == first and hi == first + n_new, "host rows and device rows out of step"
@@ -273,6 +313,7 @@ class HipVectorStore(BaseVDB):
                 table.live[pos] = True
                 table.rows.append(row)
                 table.pk_map[pk] = pos
+                table.note_insert(pos, row)
         return row
 
     async def clean_table(self, table_name: str, where: Dict[str, Any]) -> bool:
@@ -291,15 +332,23 @@ class HipVectorStore(BaseVDB):
         if unknown:
             raise AttributeError(f"table {table_name} has no column {unknown[0]!r}")
         async with self._lock:
+            candidates = None
+            for k, v in where.items():  # narrow by the first condition that has (or can get) an index
+                candidates = table.positions_where(k, [v])
+                if candidates is not None:
+                    break
+            if candidates is None:
+                candidates = range(len(table.rows))
             hit = [
                 pos
-                for pos, row in enumerate(table.rows)
-                if row is not None and all(row.get(k) == v for k, v in where.items())
+                for pos in candidates
+                if table.rows[pos] is not None and all(table.rows[pos].get(k) == v for k, v in where.items())
             ]
             if hit:
                 for pos in hit:
                     row = table.rows[pos]
                     table.pk_map.pop(tuple(row.get(c) for c in table.pk), None)
+                    table.note_delete(pos, row)
                     table.rows[pos] = None
                     table.live[pos] = False
                 if table.index is not None:
@@ -452,7 +501,9 @@ class HipVectorStore(BaseVDB):
         use_ws = bool(workspace_id) and "workspaceId" in table.colset
         use_kb = bool(knowledge_base_id) and "knowledgeBaseId" in table.colset
         hits: List[int] = []
-        for pos, row in enumerate(table.rows):
+        candidates = table.positions_where(key_column, wanted) if wanted is not None else None
+        for pos in (candidates if candidates is not None else range(len(table.rows))):
+            row = table.rows[pos]
             if row is None:
                 continue
             if wanted is not None and row.get(key_column) not in wanted:
@@ -482,9 +533,11 @@ class HipVectorStore(BaseVDB):
     async def get_existing_document_keys(self, uri: str, workspace_id: str, knowledge_base_id: str, table_name: str) -> List[str]:
         """``documentKey`` of every row with this uri / workspace / knowledge base (pgvector.py:662-683)."""
         table = self.get_model(table_name)
+        candidates = table.positions_where("uri", [uri]) if "uri" in table.colset else None
+        rows = table.rows if candidates is None else [table.rows[pos] for pos in candidates]
         return [
             row.get("documentKey")
-            for row in table.rows
+            for row in rows
             if row is not None
             and row.get("uri") == uri
             and row.get("workspaceId") == workspace_id
@@ -557,6 +610,7 @@ class HipVectorStore(BaseVDB):
                     for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
                         setattr(table, col, getattr(table, col)[:n][keep].copy())
                     table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
+                    table.key_index.clear()
                 out[name] = len(table.rows)
         return out
 

@@ -297,3 +297,26 @@ def test_tombstones_compaction_and_snapshot(hvs, dtype, tmp_path):
     assert len(e2) == 0
     e2.close()
     empty.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_dimension_4096(hvs, dtype):
+    """EMBEDDING_DIMENSION = 4096 (the reference's Qwen3 setting, .env.example:14): every path at that width,
+    including four embeddings folded by LEAST (the query staging no longer fits eight at once)."""
+    rng = np.random.default_rng(4096)
+    n, d = 3000, 4096
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((8, d)).astype(np.float32)
+    idx = _mk(hvs, rows, dtype)
+    dm = parity.distance_matrix(rows, q, dtype)
+    for algo in ("scan", "mfma"):
+        dist, ids, cnt = idx.search(q, k=10, algo=algo)
+        for i in range(8):
+            parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, label=f"d4096 {dtype} {algo} q={i}")
+        dist, ids, cnt = idx.search(q, k=10, fold=4, max_distance=1.1, algo=algo)
+        for i in range(2):
+            parity.check_topk(dist[i], ids[i], cnt[i], po.least_fold(dm[4 * i : 4 * i + 4]), 10, threshold=1.1,
+                              label=f"d4096 fold4 {dtype} {algo} q={i}")
+    col = idx.distances(q[:3])
+    np.testing.assert_allclose(col, po.least_fold(dm[:3]), atol=1e-5)
+    idx.close()
