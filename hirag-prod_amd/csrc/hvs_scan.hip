@@ -98,6 +98,31 @@ template <> struct Chunk<HVS_BF16> {
     }
 };
 
+// ---- 16-bit rows, two to four embeddings: v_mfma_f32_4x4x4_16B_{f16,bf16} -------------------------
+// The instruction multiplies 16 independent blocks: D_b[i][j] += sum_k A_b[i][k] B_b[k][j], i, j, k < 4.
+// Lane 4 b + i supplies A_b[i][0..3], lane 4 b + j supplies B_b[0..3][j] and receives D_b[0..3][j].  With
+// A = four embeddings and B = four rows, both at the same four elements, one instruction does the work
+// of sixteen dot2 instructions and the scan stays bandwidth-bound with several embeddings.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int DT> __device__ __forceinline__ f32x4v mfma4(const u32x4 &q, const u32x4 &v, f32x4v acc) {
+    uint32_t qa[4] = {q.x, q.y, q.z, q.w}, va[4] = {v.x, v.y, v.z, v.w};
+    if (DT == HVS_F16) {
+        h16x4 a[2], b[2];
+        __builtin_memcpy(a, qa, 16);
+        __builtin_memcpy(b, va, 16);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4f16(a[0], b[0], acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_4x4x4f16(a[1], b[1], acc, 0, 0, 0);
+    } else {
+        s16x4 a[2], b[2];
+        __builtin_memcpy(a, qa, 16);
+        __builtin_memcpy(b, va, 16);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[0], b[0], acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a[1], b[1], acc, 0, 0, 0);
+    }
+}
+
 // ---- wave-private sorted list in LDS ------------------------------------------------------------
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -154,7 +179,8 @@ __device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k
 // the number of sums a lane carries (it keeps one half and hands the other to its partner), the remaining
 // steps are plain butterflies on the one sum left: V - 1 + log2(W / V) shuffles.  Afterwards the total of
 // sum j sits in a[0] of every lane whose index inside the group, shifted right by log2(W / V), equals j.
-template <int V, int W> __device__ __forceinline__ void reduce_scatter(float (&a)[V], int l) {
+// STRIDE: distance in lanes between neighbours of a group (l = lane / STRIDE % W).
+template <int V, int W, int STRIDE = 1> __device__ __forceinline__ void reduce_scatter(float (&a)[V], int l) {
     int n = V;
 #pragma unroll
     for (int o = W / 2; o >= 1; o >>= 1) {
@@ -166,12 +192,12 @@ template <int V, int W> __device__ __forceinline__ void reduce_scatter(float (&a
                 if (i < half) {
                     const float send = upper ? a[i] : a[i + half];
                     const float keep = upper ? a[i + half] : a[i];
-                    a[i] = keep + __shfl_xor(send, o);
+                    a[i] = keep + __shfl_xor(send, o * STRIDE);
                 }
             }
             n = half;
         } else {
-            a[0] += __shfl_xor(a[0], o);
+            a[0] += __shfl_xor(a[0], o * STRIDE);
         }
     }
 }
@@ -180,25 +206,29 @@ constexpr int hvs_log2(int v) { return v <= 1 ? 0 : 1 + hvs_log2(v / 2); }
 
 // ---- the scan -----------------------------------------------------------------------------------
 // LPR = lanes per row: 64 (one row per wave pass) or 32 (two rows per pass, for rows of <= 2 KB, which
-// would otherwise leave half the lanes idle and pay the reduction and selection once per 1.5 KB).
+// would otherwise leave half the lanes idle and pay the reduction and selection once per 1.5 KB), or 16
+// for the 4x4x4 MFMA mode of 16-bit rows with up to four embeddings (NQ = 4): four rows per pass, lane
+// 4 b + j works on row j and on the b-th 16-byte chunk of every 256 bytes.
 template <int DT, int NQ, int LPR, bool DISTONLY>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
+__global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(ScanParams p) {  // <= 128 VGPRs up to four embeddings: 4 waves per SIMD
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [NQ][ld] query elements in the row's element type, then per-wave lists [SCAN_WAVES][nq_out][k] keys
     constexpr int ESZ = Chunk<DT>::ESZ;
     char *q_lds = smem;
     const int q_bytes = NQ * p.ld * ESZ;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_bytes + 15) & ~(size_t)15));
-    uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * 8]
+    uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * RG]
 
-    constexpr int R = scan_rows_in_flight(NQ);
+    constexpr bool M4 = LPR == 16;
+    static_assert(!M4 || (NQ == 4 && DT != HVS_F32 && !DISTONLY), "the 4x4x4 MFMA mode takes four 16-bit embeddings");
+    constexpr int R = M4 ? 4 : scan_rows_in_flight(NQ);
     constexpr int SUB = 64 / LPR;     // rows per wave pass
     constexpr int RG = R * SUB;  // rows per wave iteration
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int sub = lane / LPR;
-    const int l = lane % LPR;
+    const int sub = M4 ? (lane & 3) : lane / LPR;   // row of the pass this lane works on
+    const int l = M4 ? (lane >> 2) : lane % LPR;    // its position among the LPR lanes of that row
     const int nq_total = p.nq_out * p.fold;
 
     for (int i = tid; i < NQ * p.ld; i += SCAN_THREADS) {
@@ -232,7 +262,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
     const int64_t my_groups = n_groups > gwave ? (n_groups - gwave + nwaves - 1) / nwaves : 0;
     const int64_t n_spans = (p.row_end - p.row_begin + 64 * RG - 1) / (64 * RG);
     const int64_t n_outer = filtered ? (n_spans > gwave ? (n_spans - gwave + nwaves - 1) / nwaves : 0) : (my_groups + 63) / 64;
-    volatile uint32_t *rowq = row_queue + wave * (64 * 8);
+    volatile uint32_t *rowq = row_queue + wave * (64 * RG);
     for (int64_t ob = 0; ob < n_outer; ob++) {
         const int64_t base = ob * 64;
         int n_items;
@@ -283,32 +313,61 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
                 live[r] = rowv[r] < p.row_end;
             }
         }
-        typename Chunk<DT>::Acc part[R][NQ];
+        float acc[R][NQ];
+        if (M4) {
+            if constexpr (M4) {
+                f32x4v part4[R];  // [embedding] partial sums of this lane's row over its chunks
 #pragma unroll
-        for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++) part4[r] = (f32x4v){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+                for (int c = l; c < p.chunks; c += LPR) {
+                    u32x4 v[R];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) part[r][q] = Chunk<DT>::zero();
+                    for (int r = 0; r < R; r++) {
+                        v[r] = (u32x4){0u, 0u, 0u, 0u};
+                        if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                    }
+                    // this lane supplies embedding `sub` (rows of A) and row `sub` (columns of B)
+                    const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)sub * p.chunks + c) * 16);
+#pragma unroll
+                    for (int r = 0; r < R; r++) part4[r] = mfma4<DT>(qv, v[r], part4[r]);
+                }
+                // sum over the 16 lanes of the row (lane stride 4), then hand every lane of the row all four totals
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    float a[4] = {part4[r][0], part4[r][1], part4[r][2], part4[r][3]};
+                    reduce_scatter<4, 16, 4>(a, l);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) acc[r][q] = __shfl(a[0], (q << 4) | sub);
+                }
+            }
+        } else {
+            typename Chunk<DT>::Acc part[R][NQ];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int q = 0; q < NQ; q++) part[r][q] = Chunk<DT>::zero();
 
 #pragma unroll 2
-        for (int c = l; c < p.chunks; c += LPR) {
-            u32x4 v[R];
+            for (int c = l; c < p.chunks; c += LPR) {
+                u32x4 v[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                v[r] = (u32x4){0u, 0u, 0u, 0u};
-                if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                for (int r = 0; r < R; r++) {
+                    v[r] = (u32x4){0u, 0u, 0u, 0u};
+                    if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
+#pragma unroll
+                    for (int r = 0; r < R; r++) part[r][q] = Chunk<DT>::dot(v[r], qv, part[r][q]);
+                }
             }
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
+            for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int r = 0; r < R; r++) part[r][q] = Chunk<DT>::dot(v[r], qv, part[r][q]);
-            }
+                for (int q = 0; q < NQ; q++) acc[r][q] = Chunk<DT>::finish(part[r][q]);
         }
-        float acc[R][NQ];
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-            for (int q = 0; q < NQ; q++) acc[r][q] = Chunk<DT>::finish(part[r][q]);
         if (NQ == 1) {
             // One query: the tail below costs as much as the row stream hides, so it is kept short.
             // add up the R * NQ partial sums over the LPR lanes of the row group, then hand every lane of
@@ -363,15 +422,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(ScanParams p) {
             // Several embeddings: rows are finished one at a time, which keeps few values alive (registers
             // decide the occupancy here).
             // butterfly inside each group of LPR lanes: every lane ends with its row's full dot products
+            if (!M4) {
     #pragma unroll
-            for (int r = 0; r < R; r++)
+                for (int r = 0; r < R; r++)
     #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    float s = acc[r][q];
+                    for (int q = 0; q < NQ; q++) {
+                        float s = acc[r][q];
     #pragma unroll
-                    for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
-                    acc[r][q] = s;
-                }
+                        for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off);
+                        acc[r][q] = s;
+                    }
+            }
     #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int64_t row = rowv[r];
@@ -627,6 +688,10 @@ static int launch_scan(int dtype, int NQ, int lpr, int64_t want, size_t lds, hip
         if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, 64, DISTONLY>(NQ, want, lds, s, p, grid, dry);
         return launch_scan_nq<HVS_BF16, 64, DISTONLY>(NQ, want, lds, s, p, grid, dry);
     }
+    if (lpr == 16) {
+        if (dtype == HVS_F16) return launch_scan_one<HVS_F16, 4, 16, false>(want, lds, s, p, grid, dry);
+        return launch_scan_one<HVS_BF16, 4, 16, false>(want, lds, s, p, grid, dry);
+    }
     if (dtype == HVS_F32) return launch_scan_nq<HVS_F32, 32, false>(NQ, want, lds, s, p, grid, dry);
     if (dtype == HVS_F16) return launch_scan_nq<HVS_F16, 32, false>(NQ, want, lds, s, p, grid, dry);
     return launch_scan_nq<HVS_BF16, 32, false>(NQ, want, lds, s, p, grid, dry);
@@ -634,10 +699,11 @@ static int launch_scan(int dtype, int NQ, int lpr, int64_t want, size_t lds, hip
 
 static inline int round_nq(int n) { return n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8)); }
 
-static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k) {
+// rg = rows a wave takes per iteration (sizes the live-row queue of filtered scans)
+static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k, int rg) {
     size_t b = ((size_t)NQ * ld * esz + 15) & ~(size_t)15;
     b += (size_t)SCAN_WAVES * nq_out * k * 8;
-    b += (size_t)SCAN_WAVES * 64 * 8 * 4;  // live-row queues
+    b += (size_t)SCAN_WAVES * 64 * rg * 4;  // live-row queues
     return b;
 }
 
@@ -647,19 +713,24 @@ static const size_t LDS_LIMIT = 160 * 1024;
 int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
                     int64_t *d_ids, int32_t *d_count) {
-    // out-queries per pass: as many as fit 8 dot products and the LDS budget
-    int per_pass = 8 / fold;
+    // out-queries per pass: as many as fit 8 dot products and the LDS budget -- or 4, for 16-bit rows with
+    // two to four embeddings per query: those passes run the 4x4x4 MFMA mode, which stays bandwidth-bound
+    const bool m4 = idx->dtype != HVS_F32 && fold <= 4 && nq * fold >= 2;
+    int per_pass = (m4 ? 4 : 8) / fold;
     if (per_pass < 1) per_pass = 1;
     if (per_pass > nq) per_pass = nq;
-    while (per_pass > 1 && scan_lds_bytes(round_nq(per_pass * fold), idx->ld, idx->elem_size, per_pass, k) > LDS_LIMIT / 2) per_pass--;
-    const int NQ = round_nq(per_pass * fold);
-    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, per_pass, k);
+    const int chunks = idx->ld * idx->elem_size / 16;
+    const int lpr = m4 ? 16 : scan_lpr(chunks);
+    auto rows_per_iter_of = [&](int nq_rounded) { return m4 ? 16 : scan_rows_in_flight(nq_rounded) * (64 / lpr); };
+    while (per_pass > 1 && scan_lds_bytes(m4 ? 4 : round_nq(per_pass * fold), idx->ld, idx->elem_size, per_pass, k,
+                                          rows_per_iter_of(round_nq(per_pass * fold))) > LDS_LIMIT / 2)
+        per_pass--;
+    const int NQ = m4 ? 4 : round_nq(per_pass * fold);
+    const int rows_per_iter = rows_per_iter_of(NQ);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, per_pass, k, rows_per_iter);
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_search: dim %d with fold %d and k %d needs %zu bytes of LDS (limit %zu)", idx->dim, fold, k, lds, LDS_LIMIT);
 
-    const int chunks = idx->ld * idx->elem_size / 16;
-    const int lpr = scan_lpr(chunks);
     const int64_t n_rows = row_end - row_begin;
-    const int rows_per_iter = scan_rows_in_flight(NQ) * (64 / lpr);
     const int64_t row_groups = (n_rows + rows_per_iter - 1) / rows_per_iter;
     const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
     int grid = 0;
@@ -810,7 +881,7 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
         d_out = (float *)stage;
     }
     const int NQ = round_nq(fold);
-    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, 1, 1);
+    const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, 1, 1, scan_rows_in_flight(NQ));
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_distances: dim %d with fold %d needs %zu bytes of LDS", idx->dim, fold, lds);
     ScanParams p;
     memset(&p, 0, sizeof(p));
