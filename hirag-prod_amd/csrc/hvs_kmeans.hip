@@ -166,23 +166,7 @@ __global__ void prep_centroids_kernel(const float *__restrict__ src, float *__re
     if (lane == 0) c_norm[j] = s;
 }
 
-// M-step partial sums: one wave per row, 256-byte contiguous float atomics into sums[assign[r]];
-// counts through a per-block LDS histogram when K fits, else direct atomics.
-__global__ __launch_bounds__(256) void kmeans_accumulate_kernel(const float *__restrict__ X, const int32_t *__restrict__ assign,
-                                                                int64_t n, int dim, int ld, int K, float *sums,
-                                                                unsigned long long *counts) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t r = wave; r < n; r += nwaves) {
-        const int a = assign[r];
-        if (a < 0) continue;
-        const float *x = X + (size_t)r * ld;
-        float *dst = sums + (size_t)a * dim;
-        for (int c = lane; c < dim; c += 64) atomicAdd(dst + c, x[c]);
-        if (lane == 0) atomicAdd(counts + a, 1ull);
-    }
-}
+int hvs_kmeans_update(hvs_index *idx, const int32_t *d_assign, int64_t n, int K, float *d_sums, int64_t *d_counts);  // hvs_kmeans_update.hip
 
 static size_t assign_lds_bytes() { return (size_t)2 * KT::STAGE_BYTES + KT::BM * 4 + 2 * 64 * 8; }
 
@@ -268,12 +252,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_KMEANS_ASSIGN));
 
     if (out_sums) {
-        HVS_HIP(hipMemsetAsync(d_sums, 0, (size_t)K * dim * 4, st));
-        HVS_HIP(hipMemsetAsync(d_counts, 0, (size_t)K * 8, st));
         HVS_TRY(hvs_prof_begin(idx));
-        kmeans_accumulate_kernel<<<256 * 8, 256, 0, st>>>((const float *)idx->rows, d_assign, n, dim, ld, K, d_sums,
-                                                          (unsigned long long *)d_counts);
-        HVS_HIP(hipGetLastError());
+        HVS_TRY(hvs_kmeans_update(idx, d_assign, n, K, d_sums, d_counts));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_KMEANS_UPDATE));
     }
     if (!on_device) {

@@ -187,3 +187,28 @@ def test_kmeans_golden(hvs, golden_dir):
         new_c = sums / np.maximum(counts, 1)[:, None]
         np.testing.assert_allclose(new_c, g["centers1"], atol=1e-4)
         idx.close()
+
+
+def test_kmeans_sums_are_reproducible_and_cover_small_k(hvs):
+    """The M-step sums add a centroid's rows in ascending row order: two runs give the same bits; a
+    handful of big clusters (sliced over many blocks) and deleted rows are handled too."""
+    rng = np.random.default_rng(12)
+    n, d = 20_000, 70
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    gone = np.arange(5, n, 97)
+    idx.set_deleted(gone, True)
+    for kc in (3, 257):
+        cent = rows[rng.choice(n, kc, replace=False)].copy()
+        a1, s1, c1 = idx.kmeans_assign(cent)
+        a2, s2, c2 = idx.kmeans_assign(cent)
+        np.testing.assert_array_equal(a1, a2)
+        np.testing.assert_array_equal(s1, s2)  # bit for bit
+        np.testing.assert_array_equal(c1, c2)
+        assert np.all(a1[gone] == -1) and int(c1.sum()) == n - len(gone)
+        live = a1 >= 0
+        _, exp_sums, exp_counts = kmeans_oracle.update(rows[live], a1[live], cent)
+        np.testing.assert_array_equal(c1, exp_counts)
+        np.testing.assert_allclose(s1, exp_sums, rtol=1e-4, atol=1e-3)
+    idx.close()
