@@ -1,4 +1,5 @@
-// k-means E-step (argmin over centroids) on the fp32 MFMA tile machinery, plus the M-step partial sums.
+// k-means E-step (argmin over centroids) on the fp32 MFMA tile machinery; the M-step partial sums are in
+// hvs_kmeans_update.hip.
 //
 // assign[r] = argmin_j |x_r - c_j|^2 = argmin_j (|c_j|^2 - 2 x_r . c_j), lowest j on ties.
 // Blocks own a 128-centroid tile and stream the corpus (the blocks of the 8 XCD groups that share a

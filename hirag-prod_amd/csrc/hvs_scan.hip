@@ -1,12 +1,12 @@
 // Bandwidth-bound exact scan (GEMV) with a fused wavefront-level top-k, the list-merge kernels and
 // the hvs_search / hvs_distances / hvs_merge_topk entry points.
 //
-// Data flow of one search:  rows stream HBM -> VGPRs exactly once (16 B per lane per load, one wave
-// per row, R rows in flight per wave); the query embeddings sit in LDS as fp32; every wave keeps a
-// sorted top-k list per query in LDS and only touches it when a row beats the list's current worst
-// (rare after the first few hundred rows), so the score vector is never written anywhere.  Each
-// block then folds its waves' lists into one and writes k keys; log_32(P) tiny merge launches reduce
-// the P block lists to the final answer.
+// Data flow of one search:  rows stream HBM -> VGPRs exactly once (16 B per lane per load, 16 to 64
+// lanes per row, several rows in flight per wave); the query embeddings sit in LDS in the rows' own
+// element type; every wave keeps a sorted top-k list per query in LDS and only touches it when a row
+// beats the list's current worst (rare after the first few hundred rows), so the score vector is never
+// written anywhere.  Every wave then writes its k keys; log_32(P) tiny merge launches reduce the P wave
+// lists to the final answer.
 #include "hvs_internal.h"
 
 #define SCAN_THREADS 256
