@@ -5,8 +5,8 @@
  * sends SQL to PostgreSQL and the pgvector extension computes
  * "vector <=> query ... ORDER BY distance LIMIT k" server-side.  Each entry
  * point below names the reference interface whose work it takes over; the
- * Python host side (hirag-prod_amd/store.py) binds them with ctypes exactly
- * as INTEGRATION.md shows.
+ * Python host side (hirag-prod_amd/_lib.py, used by index.py and store.py)
+ * binds them with ctypes.
  *
  * Conventions
  *   - every function returns 0 on success, non-zero on failure; the message
