@@ -52,6 +52,8 @@ SIGNATURES = {
     "hvs_index_deleted_count": (c_int, [c_void_p, POINTER(c_int64)]),
     "hvs_index_compact": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "hvs_index_export": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hvs_range_search": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int32, c_void_p, c_double, c_int64, c_int64, c_int64, c_void_p,
+                                 c_void_p, POINTER(c_int64), c_int]),
     "hvs_cosine_matrix": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int]),
     "hvs_kmeans_assign": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "hvs_profile_enable": (c_int, [c_void_p, c_int]),

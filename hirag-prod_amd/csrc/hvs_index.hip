@@ -214,7 +214,34 @@ __device__ __forceinline__ bool row_is_live(const hvs_live_params &p, int64_t ro
     if (p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
     if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
     if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
+    if (ok && p.dist) ok = p.dist[row - p.row_begin] < p.max_dist;  // false for NaN
     return ok;
+}
+
+__global__ void range_gather_kernel(const uint32_t *__restrict__ positions, int64_t n, const float *__restrict__ dist,
+                                    int64_t row_begin, const int64_t *__restrict__ ids, float *__restrict__ out_dist,
+                                    int64_t *__restrict__ out_ids) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t r = positions[i];
+        out_dist[i] = dist[r - row_begin];
+        out_ids[i] = ids[r];
+    }
+}
+
+int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
+                      int64_t *total) {
+    uint32_t n_hit = 0;
+    HVS_TRY(hvs_live_count(idx, lp, &n_hit));
+    *total = n_hit;
+    if (n_hit == 0 || capacity <= 0) return 0;
+    void *pos = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 6, (size_t)n_hit * 4 + 256, &pos));
+    HVS_TRY(hvs_live_write(idx, lp, (uint32_t *)pos));
+    const int64_t m = (int64_t)n_hit < capacity ? (int64_t)n_hit : capacity;
+    range_gather_kernel<<<grid_for(m), 256, 0, idx->stream>>>((const uint32_t *)pos, m, lp.dist, lp.row_begin, idx->ids, d_out_dist,
+                                                             d_out_ids);
+    HVS_HIP(hipGetLastError());
+    return 0;
 }
 
 // Thread t of block b looks at rows b * LIVE_CHUNK + i * LIVE_THREADS + t (coalesced); a block's rows are

@@ -89,10 +89,15 @@ struct hvs_live_params {
     const uint32_t *deleted;  // optional: bit set = row deleted
     int32_t group_filter;     // -1 = any group
     int64_t row_begin, row_end;
+    const float *dist = nullptr;  // optional: distance of row r at dist[r - row_begin]; the row passes only if it is < max_dist
+    float max_dist = 0.0f;
 };
 int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live);          // synchronises the stream
 int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *positions);        // after hvs_live_count
 int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv);
+// (distance, id) of the rows that pass lp (lp.dist set), ascending row position, first `capacity` of them; *total = all
+int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
+                      int64_t *total);
 
 #define HVS_ROWS_SLACK 256  // zeroed bytes kept after the last row of a row matrix (see hvs_index_reserve)
 

@@ -862,27 +862,15 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     return 0;
 }
 
-extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int64_t row_begin, int64_t row_end,
-                             float *out, int on_device) {
-    HVS_REQUIRE(idx != nullptr, "hvs_distances: idx is NULL");
-    HVS_REQUIRE(queries && out, "hvs_distances: NULL argument");
-    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_distances: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
-    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
-    if (row_begin < 0) row_begin = 0;
-    if (row_begin >= row_end) return 0;
-    HVS_HIP(hipSetDevice(idx->device));
+// distance column of rows [row_begin, row_end) into the device buffer d_out (queries as hvs_distances takes them)
+static int distance_column(hvs_index *idx, const float *queries, int fold, int on_device, int64_t row_begin, int64_t row_end,
+                           float *d_out, const char *who) {
     float *d_q = nullptr, *d_qinv = nullptr;
     HVS_TRY(hvs_prepare_queries(idx, queries, fold, on_device, &d_q, &d_qinv));
     const int64_t n_rows = row_end - row_begin;
-    float *d_out = out;
-    if (!on_device) {
-        void *stage = nullptr;
-        HVS_TRY(hvs_ws_get(idx, 3, (size_t)n_rows * 4, &stage));
-        d_out = (float *)stage;
-    }
     const int NQ = round_nq(fold);
     const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, 1, 1, scan_rows_in_flight(NQ));
-    HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_distances: dim %d with fold %d needs %zu bytes of LDS", idx->dim, fold, lds);
+    HVS_REQUIRE(lds <= LDS_LIMIT, "%s: dim %d with fold %d needs %zu bytes of LDS", who, idx->dim, fold, lds);
     ScanParams p;
     memset(&p, 0, sizeof(p));
     p.rows = idx->rows;
@@ -904,10 +892,74 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
     HVS_TRY(hvs_prof_begin(idx));
     HVS_TRY(launch_scan<true>(idx->dtype, NQ, 64, want_blocks, lds, idx->stream, p, &grid, false));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
+    return 0;
+}
+
+extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int64_t row_begin, int64_t row_end,
+                             float *out, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_distances: idx is NULL");
+    HVS_REQUIRE(queries && out, "hvs_distances: NULL argument");
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_distances: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_begin >= row_end) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    const int64_t n_rows = row_end - row_begin;
+    float *d_out = out;
+    if (!on_device) {
+        void *stage = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 3, (size_t)n_rows * 4, &stage));
+        d_out = (float *)stage;
+    }
+    HVS_TRY(distance_column(idx, queries, fold, on_device, row_begin, row_end, d_out, "hvs_distances"));
     if (!on_device) {
         HVS_HIP(hipMemcpyAsync(out, d_out, (size_t)n_rows * 4, hipMemcpyDeviceToHost, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));
     }
+    return 0;
+}
+
+extern "C" int hvs_range_search(hvs_index *idx, const float *queries, int fold, int32_t group_filter, const uint32_t *row_mask,
+                                double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity, float *out_dist,
+                                int64_t *out_ids, int64_t *out_total, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_range_search: idx is NULL");
+    HVS_REQUIRE(queries && out_total, "hvs_range_search: NULL argument");
+    HVS_REQUIRE(capacity >= 0 && (capacity == 0 || (out_dist && out_ids)), "hvs_range_search: outputs missing for capacity %lld", (long long)capacity);
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_range_search: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    int64_t total = 0;
+    if (row_begin < row_end) {
+        HVS_HIP(hipSetDevice(idx->device));
+        const int64_t n_rows = row_end - row_begin;
+        // staging (workspace 3): [distance column][mask words, if they come from the host][outputs, if they go to the host]
+        const size_t mask_bytes = (row_mask && !on_device) ? (size_t)((idx->n + 31) / 32) * 4 : 0;
+        const size_t o_mask = ((size_t)n_rows * 4 + 255) & ~(size_t)255;
+        const size_t o_dist = (o_mask + mask_bytes + 255) & ~(size_t)255;
+        const size_t o_ids = (o_dist + (on_device ? 0 : (size_t)capacity * 4) + 255) & ~(size_t)255;
+        void *stage = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 3, o_ids + (on_device ? 0 : (size_t)capacity * 8) + 256, &stage));
+        float *d_col = (float *)stage;
+        const uint32_t *d_mask = row_mask;
+        if (mask_bytes) {
+            HVS_HIP(hipMemcpyAsync((char *)stage + o_mask, row_mask, mask_bytes, hipMemcpyHostToDevice, idx->stream));
+            d_mask = (const uint32_t *)((char *)stage + o_mask);
+        }
+        HVS_TRY(distance_column(idx, queries, fold, on_device, row_begin, row_end, d_col, "hvs_range_search"));
+        hvs_live_params lp{idx->groups, d_mask, idx->n_deleted > 0 ? idx->deleted : nullptr, group_filter, row_begin, row_end};
+        lp.dist = d_col;
+        lp.max_dist = hvs_ceil_to_float(max_distance);
+        float *d_od = on_device ? out_dist : (float *)((char *)stage + o_dist);
+        int64_t *d_oi = on_device ? out_ids : (int64_t *)((char *)stage + o_ids);
+        HVS_TRY(hvs_range_collect(idx, lp, capacity, d_od, d_oi, &total));
+        const int64_t m = total < capacity ? total : capacity;
+        if (!on_device && m > 0) {
+            HVS_HIP(hipMemcpyAsync(out_dist, d_od, (size_t)m * 4, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipMemcpyAsync(out_ids, d_oi, (size_t)m * 8, hipMemcpyDeviceToHost, idx->stream));
+        }
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    *out_total = total;
     return 0;
 }
 

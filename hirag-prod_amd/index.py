@@ -209,6 +209,34 @@ class HvsIndex:
             check(self._lib.hvs_distances(self._h, _np_ptr(q), q.shape[0], row_begin, row_end, _np_ptr(out), 0))
         return out
 
+    def range_search(self, queries, max_distance: float, group_filter: int = -1, row_mask=None, row_begin: int = 0,
+                     row_end: int = -1, capacity: int | None = None):
+        """Every live row with ``LEAST_j(row <=> q_j) < max_distance`` in ascending row position: the rows
+        the reference keeps from its projected distance column
+        (cross_language_search/functions.py:330-340).  Returns ``(dist f32, ids i64, total)``; with a
+        ``capacity`` smaller than ``total`` only the first ``capacity`` rows come back."""
+        q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries)), dtype=np.float32)
+        if q.shape[1] != self.dim:
+            raise ValueError(f"queries must be [m, {self.dim}]")
+        mask = None
+        if row_mask is not None:
+            mask = np.ascontiguousarray(row_mask, dtype=np.uint32)
+            if mask.size < (len(self) + 31) // 32:
+                raise ValueError("row_mask has fewer bits than the index has rows")
+        total = ctypes.c_int64(0)
+        with self._lock:
+            if capacity is None:  # size the outputs from a counting call
+                check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
+                                                 row_begin, row_end, 0, None, None, ctypes.byref(total), 0))
+                capacity = total.value
+            dist = np.empty((capacity,), dtype=np.float32)
+            ids = np.empty((capacity,), dtype=np.int64)
+            if capacity > 0:
+                check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
+                                                 row_begin, row_end, capacity, _np_ptr(dist), _np_ptr(ids), ctypes.byref(total), 0))
+        m = min(capacity, total.value)
+        return dist[:m], ids[:m], total.value
+
     def gather(self, positions) -> np.ndarray:
         """Stored vectors at the given row positions, widened to float32 ``[n, dim]``."""
         pos = np.ascontiguousarray(positions, dtype=np.int64)

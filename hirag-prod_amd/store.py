@@ -563,16 +563,38 @@ class HipVectorStore(BaseVDB):
     # -- the full distance column (cross-language search) ------------------------------------------
     async def query_distance_column(self, embeddings, workspace_id: str, knowledge_base_id: str,
                                     table_name: str = "Items", columns_to_select: Optional[List[str]] = None,
-                                    column_name: str = "search_sentence_cosine_distance") -> List[dict]:
+                                    column_name: str = "search_sentence_cosine_distance",
+                                    max_distance: Optional[float] = None) -> List[dict]:
         """Every row of one knowledge base with ``LEAST_i(vector <=> e_i)`` as an extra column: what
         ``cross_language_search`` selects through ``additional_data_to_select``
-        (``src/hirag_prod/cross_language_search/search_service.py:100-113``), without ordering or limit."""
+        (``src/hirag_prod/cross_language_search/search_service.py:100-113``), without ordering or limit.
+        With ``max_distance`` only the rows whose column is below it come back (the rows
+        ``cross_language_search/functions.py:330-340`` keeps with 0.4), selected on the GPU, so the
+        column never crosses to the host."""
         table = self.get_model(table_name)
         if columns_to_select is None:
             columns_to_select = [c for c in table.columns if c != "vector"]
         q = np.asarray([self._to_list(e) for e in embeddings], dtype=np.float32)
         if table.index is None or not len(table.rows) or q.size == 0:
             return []
+        if max_distance is not None:
+            group_filter, mask, empty = self._row_filter(table, workspace_id, knowledge_base_id, None, None)
+            if empty:
+                return []
+            best: Dict[int, float] = {}
+            for s in range(0, q.shape[0], _MAX_FOLD):  # LEAST < bound iff some group's LEAST < bound
+                dist, ids, _ = await asyncio.to_thread(table.index.range_search, q[s : s + _MAX_FOLD], float(max_distance),
+                                                       group_filter, mask)
+                for pos, d in zip(ids.tolist(), dist.tolist()):
+                    if pos not in best or d < best[pos]:
+                        best[pos] = d
+            out = []
+            for pos in sorted(best):
+                row = table.rows[pos]
+                rec = {c: row.get(c) for c in columns_to_select if c in table.colset and c != "vector"}
+                rec[column_name] = best[pos]
+                out.append(rec)
+            return out
         col = None
         for s in range(0, q.shape[0], _MAX_FOLD):
             part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_FOLD])

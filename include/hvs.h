@@ -156,6 +156,22 @@ int hvs_distances(hvs_index *idx, const float *queries, int fold,
                   int64_t row_begin, int64_t row_end, float *out, int on_device);
 
 /*
+ * Every row whose distance is below a bound: the (distance, id) pairs of the
+ * rows of [row_begin, row_end) that pass the filters and have LEAST-folded
+ * distance < max_distance (strict, NaN never passes), in ascending row
+ * position.  At most `capacity` pairs are written; *out_total (a HOST int64)
+ * receives the number of matching rows, which may exceed capacity.  The
+ * consumer of the reference's projected distance column keeps exactly these
+ * rows: `search_sentence_cosine_distance < 0.4`,
+ * cross_language_search/functions.py:330-340 over the column selected at
+ * cross_language_search/search_service.py:100-113.  The call returns after the
+ * work has completed.
+ */
+int hvs_range_search(hvs_index *idx, const float *queries, int fold, int32_t group_filter,
+                     const uint32_t *row_mask, double max_distance, int64_t row_begin, int64_t row_end,
+                     int64_t capacity, float *out_dist, int64_t *out_ids, int64_t *out_total, int on_device);
+
+/*
  * Fetch stored vectors by row position, widened to float.  Replaces selecting
  * the "vector" column in PGVector.query_by_keys (pgvector.py:606-660) as used
  * by QueryService.query_chunk_embeddings (storage/query_service.py:194-224).

@@ -68,6 +68,19 @@ class OracleIndex:
         d = np.stack([po.cosine_distance(rows_s, q_s[i]) for i in range(q.shape[0])])
         return po.least_fold(d).astype(np.float32)
 
+    def range_search(self, queries, max_distance, group_filter=-1, row_mask=None, row_begin=0, row_end=-1, capacity=None):
+        d = self.distances(queries)
+        with np.errstate(invalid="ignore"):
+            hit = self._keep(group_filter, row_mask) & (d.astype(np.float64) < max_distance)
+        n = len(self)
+        hit[:row_begin] = False
+        hit[n if row_end < 0 else row_end :] = False
+        ids = np.flatnonzero(hit).astype(np.int64)
+        total = len(ids)
+        if capacity is not None:
+            ids = ids[:capacity]
+        return d[ids], ids, total
+
     def gather(self, positions):
         return po.round_storage(self.rows[np.asarray(positions, dtype=np.int64)], self.dtype).astype(np.float32)
 

@@ -153,6 +153,15 @@ async def scenario_basic(store, storage):
     assert len(col) == sum(1 for p in props if p["workspaceId"] == "ws2")
     by_key = {c["documentKey"]: c["search_sentence_cosine_distance"] for c in col}
     assert by_key[props[4]["documentKey"]] < 1e-3 and by_key[props[8]["documentKey"]] < 1e-3
+    # ... and only the rows below a bound (what the consumer keeps), selected without shipping the column
+    finite = sorted(v for v in by_key.values() if v is not None)
+    cut = max(range(1, len(finite) - 1), key=lambda i: finite[i] - finite[i - 1])  # the widest gap: no row near the bound
+    bound = (finite[cut - 1] + finite[cut]) / 2
+    near = await store.query_distance_column([embed_text("text ws2 kb1 4"), embed_text("text ws2 kb1 8")], "ws2", "kb1",
+                                             "Chunks", columns_to_select=["documentKey"], max_distance=bound)
+    want = {k: v for k, v in by_key.items() if v is not None and v < bound}
+    assert len(want) == cut and [c["documentKey"] for c in near] == [c["documentKey"] for c in col if c["documentKey"] in want]
+    assert all(abs(c["search_sentence_cosine_distance"] - want[c["documentKey"]]) < 1e-5 for c in near)
 
     # Files table: metadata only
     f = {"documentKey": "file-1", "knowledgeBaseId": "kb1", "workspaceId": "ws1", "text": "", "fileName": "a.pdf",

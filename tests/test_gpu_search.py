@@ -320,3 +320,69 @@ def test_dimension_4096(hvs, dtype):
     col = idx.distances(q[:3])
     np.testing.assert_allclose(col, po.least_fold(dm[:3]), atol=1e-5)
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_range_search_matches_the_distance_column(hvs, dtype):
+    """Every row below a distance bound: the selection the consumer of the projected column makes
+    (``search_sentence_cosine_distance < 0.4`` in the reference), against the oracle's column."""
+    rng = np.random.default_rng(77)
+    n, d = 20011, 96
+    centre = rng.standard_normal(d).astype(np.float32)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    close = rng.random(n) < 0.2
+    rows[close] = centre + 0.6 * rows[close]  # a fifth of the table lies near the first query
+    rows[17] = 0.0  # NaN distance: never selected
+    groups = (np.arange(n) % 3).astype(np.int32)
+    idx = _mk(hvs, rows, dtype, groups)
+    idx.set_deleted(np.array([3, 4, 5, 19999]), True)
+    live = np.ones(n, bool)
+    live[[3, 4, 5, 19999]] = False
+    q = np.stack([centre, rng.standard_normal(d).astype(np.float32), np.zeros(d, np.float32)])
+    keep_bits = rng.random(n) < 0.5
+    mask = np.packbits(keep_bits, bitorder="little")
+    mask = np.concatenate([mask, np.zeros((-len(mask)) % 4, np.uint8)]).view(np.uint32)
+    for fold in (1, 3):
+        full = parity.full_distances(rows, q[:fold], dtype).astype(np.float64)
+        for thr in (0.4, 0.25, 1.0, 1e-9, 3.0):
+            for gf, use_mask, lo, hi in ((-1, False, 0, -1), (1, False, 0, -1), (-1, True, 0, -1), (2, True, 1234, 15000)):
+                keep = live.copy()
+                if gf >= 0:
+                    keep &= groups == gf
+                if use_mask:
+                    keep &= keep_bits
+                keep[:lo] = False
+                if hi >= 0:
+                    keep[hi:] = False
+                dist, ids, total = idx.range_search(q[:fold], thr, group_filter=gf, row_mask=mask if use_mask else None,
+                                                    row_begin=lo, row_end=hi)
+                with np.errstate(invalid="ignore"):
+                    sure = keep & (full < thr - 2e-6)
+                    maybe = keep & (full < thr + 2e-6)
+                got = np.zeros(n, bool)
+                got[ids] = True
+                label = f"{dtype} fold={fold} thr={thr} gf={gf} mask={use_mask}"
+                assert total == len(ids) == got.sum(), label
+                assert np.all(np.diff(ids) > 0), label  # ascending row position, no duplicates
+                assert not np.any(sure & ~got) and not np.any(got & ~maybe), label
+                np.testing.assert_allclose(dist, full[ids], atol=1e-5, err_msg=label)
+                assert np.all(dist < thr) and 17 not in ids
+    # capacity smaller than the result: a prefix, and the full count
+    dist, ids, total = idx.range_search(q[:1], 0.4)
+    assert total > 100
+    d2, i2, t2 = idx.range_search(q[:1], 0.4, capacity=100)
+    assert t2 == total and i2.tolist() == ids[:100].tolist() and d2.tolist() == dist[:100].tolist()
+    # agreement with the top-k route when k covers every hit
+    k = min(total, 512)
+    dk, ik, ck = idx.search(q[:1], k=k, max_distance=0.4, algo="scan")
+    if total <= 512:
+        assert sorted(ik[0][: ck[0]].tolist()) == ids.tolist()
+    else:
+        assert set(ik[0].tolist()) <= set(ids.tolist())
+    # nothing in range / empty range / empty index
+    assert idx.range_search(q[2:3], 0.4)[2] == 0  # zero query: every distance NaN
+    assert idx.range_search(q[:1], 0.4, row_begin=500, row_end=500)[2] == 0
+    idx.close()
+    empty = hvs.HvsIndex(d, dtype)
+    assert empty.range_search(q[:1], 0.4)[2] == 0
+    empty.close()
