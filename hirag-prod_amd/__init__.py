@@ -6,6 +6,8 @@ directory).  Public surface:
 * ``HvsIndex``        -- one embedded table resident in HBM (``index.py``)
 * ``HipVectorStore``  -- drop-in for the reference's ``BaseVDB`` / ``PGVector`` (``store.py``)
 * ``ShardedSearch`` / ``sharded_kmeans_step`` -- one process per GPU over RCCL (``sharded.py``)
+* ``HvsGraph``        -- knowledge graph in HBM + personalised PageRank (``graph.py``)
+* ``HipGraphStore`` / ``FusionQueryService`` -- graph tables and the fusion step after retrieval (``graph_store.py``)
 """
 
 from ._lib import HvsError, device_count, load_library
@@ -20,6 +22,14 @@ def __getattr__(name):
         from . import store
 
         return getattr(store, name)
+    if name in ("HvsGraph", "PowerIterationFailedConvergence"):
+        from . import graph
+
+        return getattr(graph, name)
+    if name in ("HipGraphStore", "FusionQueryService", "apply_reranking"):
+        from . import graph_store
+
+        return getattr(graph_store, name)
     if name in ("ShardedSearch", "sharded_kmeans_step", "shard_range"):
         from . import sharded
 

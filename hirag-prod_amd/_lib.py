@@ -54,6 +54,13 @@ SIGNATURES = {
     "hvs_index_export": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hvs_range_search": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int32, c_void_p, c_double, c_int64, c_int64, c_int64, c_void_p,
                                  c_void_p, POINTER(c_int64), c_int]),
+    "hvs_graph_create": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, POINTER(c_void_p)]),
+    "hvs_graph_destroy": (c_int, [c_void_p]),
+    "hvs_graph_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "hvs_graph_export": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hvs_graph_pagerank": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_double, c_int, c_double, POINTER(c_int), POINTER(c_double)]),
+    "hvs_graph_scores": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int]),
+    "hvs_graph_top_chunks": (c_int, [c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     "hvs_cosine_matrix": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int]),
     "hvs_kmeans_assign": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "hvs_profile_enable": (c_int, [c_void_p, c_int]),

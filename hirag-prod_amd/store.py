@@ -8,10 +8,11 @@ the ORDER BY ... LIMIT all run in the HIP kernels.  Row metadata (the non-vector
 the host in plain Python structures: it is what PostgreSQL would return next to the distance and
 takes no part in the arithmetic.
 
-What is NOT here: the graph tables and PageRank (``upsert_graph``, ``query_node``,
-``pagerank_top_chunks_with_reset``) and SQLAlchemy-expression arguments of ``query_by_keys``; a store
-created with ``delegate=<PGVector instance>`` forwards those calls, otherwise they raise
-``NotImplementedError``.
+The graph tables and the personalised PageRank over them (``upsert_graph``, ``query_node``,
+``pagerank_top_chunks_with_reset``, ``clean_table`` on Graph / Nodes) are served by a ``HipGraphStore``
+(``graph_store.py``) this store owns, unless it was created with ``delegate=<PGVector instance>``, which
+then receives those calls.  What is NOT here: SQLAlchemy-expression arguments of ``query_by_keys`` and
+``upsert_file_from_metadata`` (delegate or ``NotImplementedError``).
 """
 
 from __future__ import annotations
@@ -132,6 +133,7 @@ class HipVectorStore(BaseVDB):
         tokenizer: Optional[Callable[[str], tuple]] = None,
         translator: Optional[Callable[[str], Any]] = None,
         index_factory: Optional[Callable[[int, str, int], Any]] = None,
+        graph_factory: Optional[Callable[..., Any]] = None,
     ):
         if vector_type not in ("vector", "halfvec", "bf16"):
             raise ValueError(f"vector_type must be 'vector', 'halfvec' or 'bf16', got {vector_type!r}")
@@ -144,6 +146,8 @@ class HipVectorStore(BaseVDB):
         self.tokenizer = tokenizer
         self.translator = translator
         self._index_factory = index_factory
+        self._graph_factory = graph_factory
+        self._graph_store = None
         self.tables: Dict[str, _Table] = {name: _Table(name) for name in TABLES}
         self._ws_codes: Dict[str, int] = {}
         self._kb_codes: Dict[str, int] = {}
@@ -323,10 +327,10 @@ class HipVectorStore(BaseVDB):
         except NotImplementedError:
             return await self.delegate.clean_table(table_name=table_name, where=where)
         except ValueError:
-            if table_name in ("Graph", "Nodes"):  # graph tables are not held here
+            if table_name in ("Graph", "Nodes"):
                 if self.delegate is not None:
                     return await self.delegate.clean_table(table_name=table_name, where=where)
-                return False
+                return await self.graph_store.clean_table(table_name, where)
             raise
         unknown = [k for k in where if k not in table.colset]
         if unknown:
@@ -732,15 +736,25 @@ class HipVectorStore(BaseVDB):
                     raise ValueError(f"{directory}: {name}.hvs does not match the store ({len(table.index)} rows, {table.index.dtype})")
         return store
 
-    # -- delegated (graph side, not on the dense-retrieval path) -------------------------------------
+    # -- graph side ----------------------------------------------------------------------------------
+    @property
+    def graph_store(self):
+        if self._graph_store is None:
+            from .graph_store import HipGraphStore
+
+            self._graph_store = HipGraphStore(device=self.device, graph_factory=self._graph_factory)
+        return self._graph_store
+
     def __getattr__(self, name):
-        if name in ("upsert_graph", "query_node", "pagerank_top_chunks_with_reset", "upsert_file_from_metadata"):
+        if name in ("upsert_graph", "query_node", "pagerank_top_chunks_with_reset"):
+            delegate = self.__dict__.get("delegate")
+            return getattr(delegate if delegate is not None else self.graph_store, name)
+        if name == "upsert_file_from_metadata":
             delegate = self.__dict__.get("delegate")
             if delegate is not None:
                 return getattr(delegate, name)
             raise NotImplementedError(
-                f"{name} belongs to the reference's graph tables, which this store does not hold; "
-                "create it with delegate=<PGVector instance> to forward such calls"
+                f"{name} is not part of this store; create it with delegate=<PGVector instance> to forward such calls"
             )
         raise AttributeError(name)
 
@@ -757,6 +771,8 @@ class HipVectorStore(BaseVDB):
             if table.index is not None and hasattr(table.index, "close"):
                 table.index.close()
                 table.index = None
+        if self._graph_store is not None:
+            self._graph_store.close()
 
 
 __all__ = ["BaseVDB", "HipVectorStore", "StoredVector"]

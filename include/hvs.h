@@ -215,6 +215,53 @@ int hvs_cosine_matrix(int device_id, void *stream, const float *a, int m, const 
 int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids,
                       int32_t *out_assign, float *out_sums, int64_t *out_counts, int on_device);
 
+/* ---- the step after retrieval: personalised PageRank over the knowledge graph ---- */
+
+typedef struct hvs_graph hvs_graph;
+
+/*
+ * The undirected simple graph of one (workspace, knowledge base) as a CSR
+ * adjacency in device memory: what PGVector.pagerank_top_chunks_with_reset
+ * builds per query with networkx (DiGraph.add_edge over the Graph rows, then
+ * to_undirected(), src/hirag_prod/storage/pgvector.py:395-412).  src / dst
+ * hold node numbers in [0, n_nodes); parallel and antiparallel rows collapse
+ * and a self loop is one diagonal entry.  chunk_mask has one bit per node
+ * (bit j of word j/32): set when the node id starts with "chunk-"
+ * (pgvector.py:435-439).  on_device selects device or host pointers for the
+ * three arrays.  stream as in hvs_index_create.
+ */
+int hvs_graph_create(int device_id, void *stream, int64_t n_nodes, const int32_t *src, const int32_t *dst,
+                     int64_t n_edges, const uint32_t *chunk_mask, int on_device, hvs_graph **out);
+int hvs_graph_destroy(hvs_graph *g);
+/* nodes, stored adjacency entries (both directions), nodes without neighbours; any pointer may be NULL */
+int hvs_graph_info(hvs_graph *g, int64_t *n_nodes, int64_t *nnz, int64_t *n_dangling);
+/* the adjacency to HOST memory: row_ptr [n_nodes + 1], col [nnz] ascending in each row (either may be NULL) */
+int hvs_graph_export(hvs_graph *g, int64_t *row_ptr, int32_t *col);
+
+/*
+ * networkx.pagerank(G, alpha, personalization) as the reference calls it
+ * (pgvector.py:432-434; algorithm: networkx 3.3 _pagerank_scipy): float64 power
+ * iteration x <- alpha (x A + dangling(x) p) + (1 - alpha) p from x = 1/N, with
+ * A the row-normalised adjacency and p the seed weights divided by their sum,
+ * until sum|x - x_prev| < N * tol.  seed_nodes / seed_weights are HOST arrays;
+ * weights must be finite and > 0 (the caller drops the others, pgvector.py:
+ * 416-425).  The scores stay in the graph object for hvs_graph_scores /
+ * hvs_graph_top_chunks.  Returns 3 (networkx: PowerIterationFailedConvergence)
+ * when max_iter iterations do not reach the bound; the library's defaults are
+ * max_iter 100 and tol 1e-6.  out_iters / out_err may be NULL.
+ */
+int hvs_graph_pagerank(hvs_graph *g, const int32_t *seed_nodes, const double *seed_weights, int64_t n_seeds,
+                       double alpha, int max_iter, double tol, int *out_iters, double *out_err);
+/* scores of nodes [first, first + n) of the last hvs_graph_pagerank */
+int hvs_graph_scores(hvs_graph *g, int64_t first, int64_t n, double *out, int on_device);
+/*
+ * The k best chunk nodes of the last hvs_graph_pagerank by descending score,
+ * equal scores in ascending node number (the reference's stable sort over the
+ * graph's node order, pgvector.py:435-441).  HOST outputs of k entries;
+ * *out_count = min(k, chunk nodes).
+ */
+int hvs_graph_top_chunks(hvs_graph *g, int k, int32_t *out_nodes, double *out_scores, int *out_count);
+
 /* Per-kernel device time, measured with HIP events on the index's stream. */
 int hvs_profile_enable(hvs_index *idx, int on);
 int hvs_profile_get(hvs_index *idx, int which, double *total_ms, int64_t *launches);

@@ -171,11 +171,117 @@ async def scenario_basic(store, storage):
     assert await store.clean_table("Files", {"documentKey": "file-1"}) is True
     assert await store.clean_table("Graph", {"documentId": "x"}) is False
     try:
-        store.upsert_graph
+        store.upsert_file_from_metadata
     except NotImplementedError:
         pass
     else:
-        raise AssertionError("graph calls must not be silently accepted")
+        raise AssertionError("calls this store does not serve must not be silently accepted")
+
+
+class Rel:
+    """Shape of the reference's ``Relation`` dataclass (``schema/relation.py:4-8``)."""
+
+    def __init__(self, source, target, props):
+        self.source, self.target, self.properties = source, target, props
+
+
+def graph_relations(n_chunks=40, n_ent=12, ws="ws1", kb="kb1", seed=3):
+    """Chunk -> entity membership rows and entity -> entity relation rows, as the reference ingests them."""
+    rng = np.random.default_rng(seed)
+    common = {"workspaceId": ws, "knowledgeBaseId": kb, "uri": "s3://bucket/file0.pdf", "documentId": "doc-0"}
+    rels = []
+    for i in range(n_chunks):
+        for e in rng.choice(n_ent, size=3, replace=False):
+            rels.append(Rel(f"chunk-{ws}-{kb}-{i}", f"ent-{e}", {"chunkId": f"chunk-{ws}-{kb}-{i}", "target": f"Entity {e}", **common}))
+    for _ in range(20):
+        a, b = rng.choice(n_ent, size=2, replace=False)
+        rels.append(Rel(f"ent-{a}", f"ent-{b}", {"chunkId": f"chunk-{ws}-{kb}-{int(rng.integers(n_chunks))}", "source": f"Entity {a}",
+                                         "target": f"Entity {b}", "description": f"ent-{a} relates to ent-{b}", **common}))
+    return rels
+
+
+async def scenario_graph_and_fusion(store, storage):
+    """Graph ingest, personalised PageRank against the oracle, and the fusion step over both recalls."""
+    from oracle import pagerank_oracle as pro
+    from hirag_prod_amd.graph_store import FusionQueryService
+
+    await store._init_vdb(embedding_dimension=DIM)
+    props = [chunk_props(i) for i in range(40)]
+    await store.upsert_texts([p["text"] for p in props], props, "Chunks")
+    rels = graph_relations()
+    out = await store.upsert_graph(rels)
+    assert out["edges"] == len(rels) and out["nodes"] == 12
+    again = await store.upsert_graph(rels[:5])  # same primary keys: nothing new
+    assert again["edges"] == 5
+    other = await store.upsert_graph(graph_relations(n_chunks=5, n_ent=4, ws="ws2", seed=9))  # another workspace, its own graph
+    assert other["nodes"] == 4
+    node = await store.query_node("ent-3", "ws1", "kb1")
+    assert node.page_content == "Entity 3" and len(node.metadata.chunkIds) == len(set(node.metadata.chunkIds)) > 0
+    try:
+        await store.query_node("ent-99", "ws1", "kb1")
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("expected ValueError for a missing node")
+
+    # triplets: the entity -> entity rows, embedded by description (storage_manager.py:117-145)
+    trip = [r for r in rels if not r.source.startswith("chunk-")]
+    seen, t_texts, t_props = set(), [], []
+    for r in trip:
+        if (r.source, r.target, r.properties["description"]) in seen:
+            continue
+        seen.add((r.source, r.target, r.properties["description"]))
+        t_texts.append(r.properties["description"])
+        t_props.append({"source": r.source, "target": r.target, "description": r.properties["description"], "workspaceId": "ws1",
+                        "knowledgeBaseId": "kb1", "fileName": "file0.pdf", "uri": "s3://bucket/file0.pdf", "documentId": "doc-0",
+                        "documentKey": f"triplet-{len(t_props)}"})
+    await store.upsert_texts(t_texts, t_props, "Triplets")
+
+    edges = list(dict.fromkeys((r.source, r.target) for r in rels))
+    reset = {"ent-1": 2.0, "ent-5": 0.5, "chunk-ws1-kb1-7": 0.6, "missing": 4.0, "ent-2": float("nan"), "ent-3": -1.0}
+    for alpha in (0.5, 0.85):
+        got = await store.pagerank_top_chunks_with_reset("ws1", "kb1", reset, 10, alpha)
+        exp = pro.pagerank_top_chunks_with_reset(edges, reset, 10, alpha)
+        assert [n for n, _ in got] == [n for n, _ in exp], (got, exp)
+        np.testing.assert_allclose([s for _, s in got], [s for _, s in exp], rtol=0, atol=1e-12)
+    assert await store.pagerank_top_chunks_with_reset("ws1", "kb1", {"missing": 1.0}, 10) == []
+    assert await store.pagerank_top_chunks_with_reset("ws1", "kb1", reset, 0) == []
+    assert await store.pagerank_top_chunks_with_reset("nope", "kb1", reset, 10) == []
+
+    # the fusion step: both recalls together, reset weights, PageRank, rows of the ranked chunks
+    svc = FusionQueryService(store)
+    query = t_texts[0]
+    chunk_recall, triplet_recall = await svc.recall_both(query, "ws1", "kb1", topk=10, topn=5)
+    assert chunk_recall == await svc.recall_chunks(query, "ws1", "kb1", topk=10, topn=5)
+    assert triplet_recall["relations"] and triplet_recall["relations"][0]["description"] == query
+    fused = await svc.pagerank_chunks(query, chunk_recall["chunks"], "ws1", "kb1", topk=10, topn=5)
+    exp_reset, phrase = pro.fusion_reset_weights(chunk_recall["chunk_ids"], triplet_recall["relations"], triplet_recall["entity_ids"], {})
+    exp = pro.pagerank_top_chunks_with_reset(edges, exp_reset, 10, 0.5)
+    assert phrase and [r["documentKey"] for r in fused["pagerank"]] == [n for n, _ in exp]
+    np.testing.assert_allclose([r["pagerank_score"] for r in fused["pagerank"]], [s for _, s in exp], rtol=0, atol=1e-12)
+    assert fused["query_top"] == chunk_recall["chunks"] and "text" in fused["pagerank"][0]
+
+    class Reverser:  # stands in for the remote reranker
+        async def rerank(self, query, items, key="text", rerank_with_time=False):
+            return list(reversed(items))
+
+    res = await FusionQueryService(store, reranker=Reverser()).query("ws1", "kb1", query, strategy="hybrid", topk=10, topn=3)
+    assert [c["documentKey"] for c in res["chunks"]] == [n for n, _ in exp][::-1][:3]
+    assert {c["documentKey"] for c in res["outliers"]} == set(chunk_recall["chunk_ids"]) - {c["documentKey"] for c in res["chunks"]}
+    raw = await svc.query("ws1", "kb1", query, strategy="raw")
+    assert raw["chunk_ids"] == chunk_recall["chunk_ids"]
+    # no fact signal (no triplets in that workspace): the retrieval order comes back unchanged
+    nofacts = await svc.pagerank_chunks("anything", chunk_recall["chunks"], "ws2", "kb1")
+    assert nofacts["pagerank"] == [] and nofacts["query_top"] == chunk_recall["chunks"]
+
+    # deleting a document's graph rows changes the graph the next query runs on
+    assert await store.clean_table("Graph", {"source": "chunk-ws1-kb1-7"}) is True
+    edges = [e for e in edges if e[0] != "chunk-ws1-kb1-7"]
+    got = await store.pagerank_top_chunks_with_reset("ws1", "kb1", reset, 10, 0.5)
+    exp = pro.pagerank_top_chunks_with_reset(edges, reset, 10, 0.5)
+    assert [n for n, _ in got] == [n for n, _ in exp] and "chunk-ws1-kb1-7" not in [n for n, _ in got]
+    assert await store.clean_table("Nodes", {"node_id": "ent-3"}) is True
+    assert await store.clean_table("Nodes", {"node_id": "ent-3"}) is False
 
 
 async def scenario_many_embeddings(store, storage):

@@ -23,6 +23,12 @@ def test_store_basic_gpu(vector_type, storage):
     s.close()
 
 
+def test_store_graph_and_fusion_gpu():
+    s = _store("halfvec")
+    store_cases.run(store_cases.scenario_graph_and_fusion(s, "f16"))
+    s.close()
+
+
 def test_store_many_embeddings_gpu():
     s = _store("halfvec")
     store_cases.run(store_cases.scenario_many_embeddings(s, "f16"))

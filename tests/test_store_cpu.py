@@ -4,6 +4,7 @@ oracle-backed test index standing in for the GPU index."""
 import pytest
 
 from tests import store_cases
+from tests.fake_graph import make_graph
 from tests.fake_index import OracleIndex
 
 
@@ -11,12 +12,17 @@ def _store(vector_type):
     import hirag_prod_amd.store as st
 
     return st.HipVectorStore.create(store_cases.make_embedding_func(), vector_type=vector_type,
-                                    index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device))
+                                    index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device),
+                                    graph_factory=make_graph)
 
 
 @pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
 def test_store_basic(vector_type, storage):
     store_cases.run(store_cases.scenario_basic(_store(vector_type), storage))
+
+
+def test_store_graph_and_fusion():
+    store_cases.run(store_cases.scenario_graph_and_fusion(_store("halfvec"), "f16"))
 
 
 def test_store_many_embeddings():
