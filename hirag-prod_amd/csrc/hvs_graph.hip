@@ -7,7 +7,7 @@
 // pull-style sparse matrix-vector products in float64 with the library's stopping rule.
 //
 // Layout: row_ptr int64 [n+1], col int32 [nnz] (ascending in each row), inv_deg double [n] (0 for an
-// isolated node), three row lists by degree (sub-wave groups, one wave per row, one block per row), two
+// isolated node), three row lists by degree (sub-wave groups, one wave per row, several blocks per row), two
 // score vectors x and two pre-scaled copies y = x * inv_deg (so the gather reads 8 bytes per edge and
 // no degree), a dense reset vector p.
 //
@@ -29,7 +29,7 @@
 #define SMALL_LPR 8
 #define SMALL_MAX_DEG 16
 #define MID_MAX_DEG 2048
-#define BIG_THREADS 1024
+#define BIG_SEGMENT 8192
 #define TOP_BINS 4096  // sign + exponent of a double
 
 struct hvs_graph {
@@ -48,7 +48,13 @@ struct hvs_graph {
     double *partials = nullptr;  // [2][sum of blocks]: |x' - x| and dangling mass per block
     double *scal = nullptr;      // [0] err of the last iteration, [1] dangling mass of the current iterate
     int *state = nullptr;        // [0] converged flag, [1] iterations done
-    uint32_t *hist = nullptr;    // [TOP_BINS] + [2]: bin threshold, candidate count
+    uint32_t *hist = nullptr;    // [TOP_BINS] + [1]: candidate count
+    // rows of the third list are cut into segments of at most BIG_SEGMENT adjacency entries, one block each
+    int64_t *seg_begin = nullptr;   // [n_segs] first adjacency entry
+    int32_t *seg_len = nullptr;     // [n_segs]
+    int32_t *row_seg = nullptr;     // [n_rows[2] + 1] first segment of each big row
+    double *seg_sum = nullptr;      // [n_segs]
+    int64_t n_segs = 0;
     int result = -1;             // which x buffer holds the last result
     hvs_workspace ws;
 };
@@ -208,36 +214,55 @@ __global__ void __launch_bounds__(GRAPH_THREADS) ppr_rows_kernel(PprParams p, co
     block_partials<GRAPH_THREADS>(err, dang, p, slot_base + blockIdx.x);
 }
 
-// one block per row, for the few rows with very many neighbours
-__global__ void __launch_bounds__(BIG_THREADS) ppr_big_rows_kernel(PprParams p, const int32_t *__restrict__ rows, int64_t n_rows,
-                                                                   int slot_base) {
+// rows with very many neighbours: one block per segment of BIG_SEGMENT entries, then one thread per row adds the
+// row's segment sums in order
+__global__ void __launch_bounds__(GRAPH_THREADS) ppr_big_segments_kernel(PprParams p, const int64_t *__restrict__ seg_begin,
+                                                                         const int32_t *__restrict__ seg_len,
+                                                                         double *__restrict__ seg_sum) {
     if (p.state[0]) return;
-    __shared__ double s_sum[BIG_THREADS / 64];
+    __shared__ double s_sum[GRAPH_THREADS / 64];
+    const int64_t b = seg_begin[blockIdx.x];
+    const int len = seg_len[blockIdx.x];
+    const int32_t *col = p.col + b;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int t = threadIdx.x;
+    for (; t + 3 * GRAPH_THREADS < len; t += 4 * GRAPH_THREADS) {
+        s0 += p.y_in[col[t]];
+        s1 += p.y_in[col[t + GRAPH_THREADS]];
+        s2 += p.y_in[col[t + 2 * GRAPH_THREADS]];
+        s3 += p.y_in[col[t + 3 * GRAPH_THREADS]];
+    }
+    for (; t < len; t += GRAPH_THREADS) s0 += p.y_in[col[t]];
+    const double sum = wave_sum((s0 + s1) + (s2 + s3), 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double v = 0.0;
+        for (int w = 0; w < GRAPH_THREADS / 64; ++w) v += s_sum[w];
+        seg_sum[blockIdx.x] = v;
+    }
+}
+
+__global__ void __launch_bounds__(GRAPH_THREADS) ppr_big_finish_kernel(PprParams p, const int32_t *__restrict__ rows, int64_t n_rows,
+                                                                       const int32_t *__restrict__ row_seg,
+                                                                       const double *__restrict__ seg_sum, int slot_base) {
+    if (p.state[0]) return;
     const double dang_in = p.scal[1];
     double err = 0.0, dang = 0.0;
-    for (int64_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
-        const int64_t j = rows[r];
-        const int64_t b = p.row_ptr[j], e = p.row_ptr[j + 1];
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int64_t t = b + threadIdx.x;
-        for (; t + 3 * BIG_THREADS < e; t += 4 * BIG_THREADS) {
-            s0 += p.y_in[p.col[t]];
-            s1 += p.y_in[p.col[t + BIG_THREADS]];
-            s2 += p.y_in[p.col[t + 2 * BIG_THREADS]];
-            s3 += p.y_in[p.col[t + 3 * BIG_THREADS]];
-        }
-        for (; t < e; t += BIG_THREADS) s0 += p.y_in[p.col[t]];
-        double sum = wave_sum((s0 + s1) + (s2 + s3), 64);
-        __syncthreads();  // s_sum of the previous row has been read
-        if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            sum = 0.0;
-            for (int w = 0; w < BIG_THREADS / 64; ++w) sum += s_sum[w];
-            finish_row(p, j, sum, dang_in, err, dang);
-        }
+    for (int64_t r = blockIdx.x * (int64_t)GRAPH_THREADS + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * GRAPH_THREADS) {
+        double sum = 0.0;
+        for (int sgm = row_seg[r]; sgm < row_seg[r + 1]; ++sgm) sum += seg_sum[sgm];
+        finish_row(p, rows[r], sum, dang_in, err, dang);
     }
-    block_partials<BIG_THREADS>(err, dang, p, slot_base + blockIdx.x);
+    block_partials<GRAPH_THREADS>(err, dang, p, slot_base + blockIdx.x);
+}
+
+__global__ void row_degrees_kernel(const int64_t *__restrict__ row_ptr, const int32_t *__restrict__ rows, int64_t n_rows,
+                                   int64_t *__restrict__ begin, int64_t *__restrict__ degree) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x) {
+        begin[r] = row_ptr[rows[r]];
+        degree[r] = row_ptr[rows[r] + 1] - row_ptr[rows[r]];
+    }
 }
 
 // fold the per-block partials in index order; decide convergence (err < n * tol)
@@ -312,26 +337,13 @@ __global__ void __launch_bounds__(GRAPH_THREADS) top_hist_kernel(const double *_
         if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
 }
 
-// lowest bin b such that bins b.. hold at least k nodes (0 if there are fewer than k chunk nodes)
-__global__ void top_bin_kernel(uint32_t *hist, int k) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t have = 0;
-    int b = TOP_BINS - 1;
-    for (; b > 0; --b) {
-        have += hist[b];
-        if (have >= (uint64_t)k) break;
-    }
-    hist[TOP_BINS] = (uint32_t)b;
-    hist[TOP_BINS + 1] = 0;
-}
-
-__global__ void top_collect_kernel(const double *__restrict__ x, const uint32_t *__restrict__ mask, int64_t n, uint32_t *hist,
-                                   uint32_t *__restrict__ out_nodes, uint64_t *__restrict__ out_keys, uint32_t capacity) {
-    const uint32_t bin = hist[TOP_BINS];
+__global__ void top_collect_kernel(const double *__restrict__ x, const uint32_t *__restrict__ mask, int64_t n, uint32_t bin,
+                                   uint32_t *counter, uint32_t *__restrict__ out_nodes, uint64_t *__restrict__ out_keys,
+                                   uint32_t capacity) {
     for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t key = top_key(x, mask, j);
         if (key && (key >> 52) >= bin) {
-            const uint32_t at = atomicAdd(&hist[TOP_BINS + 1], 1u);
+            const uint32_t at = atomicAdd(counter, 1u);
             if (at < capacity) {
                 out_nodes[at] = (uint32_t)j;
                 out_keys[at] = key;
@@ -343,7 +355,8 @@ __global__ void top_collect_kernel(const double *__restrict__ x, const uint32_t 
 // ---- host side -----------------------------------------------------------------------------------
 static void graph_free(hvs_graph *g) {
     void *ptrs[] = {g->row_ptr, g->col, g->inv_deg, g->chunk_mask, g->rows[0], g->rows[1], g->rows[2], g->x[0], g->x[1],
-                    g->y[0], g->y[1], g->p, g->partials, g->scal, g->state, g->hist, g->ws.ptr};
+                    g->y[0], g->y[1], g->p, g->partials, g->scal, g->state, g->hist, g->seg_begin, g->seg_len, g->row_seg, g->seg_sum,
+                    g->ws.ptr};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
@@ -436,9 +449,39 @@ static int graph_build(hvs_graph *g, const int32_t *src, const int32_t *dst, int
         HVS_HIP(hipMalloc((void **)&g->rows[b], count * 4 + 4));
         HVS_HIP(hipMemcpyAsync(g->rows[b], list.p, count * 4, hipMemcpyDeviceToDevice, st));
         g->n_rows[b] = (int64_t)count;
-        const int rows_per_block = b == 0 ? GRAPH_THREADS / SMALL_LPR : (b == 1 ? GRAPH_THREADS / 64 : 1);
+        const int rows_per_block = b == 0 ? GRAPH_THREADS / SMALL_LPR : (b == 1 ? GRAPH_THREADS / 64 : GRAPH_THREADS);
         g->blocks[b] = count ? blocks_for((int64_t)count, rows_per_block) : 0;
         total_blocks += g->blocks[b];
+    }
+    if (g->n_rows[2] > 0) {  // segments of the big rows, laid out on the host (there are few such rows)
+        const int64_t nb = g->n_rows[2];
+        Scoped d_tmp;
+        HVS_HIP(hipMalloc(&d_tmp.p, (size_t)nb * 16));
+        row_degrees_kernel<<<blocks_for(nb, 256), 256, 0, st>>>(g->row_ptr, g->rows[2], nb, d_tmp.as<int64_t>(), d_tmp.as<int64_t>() + nb);
+        HVS_HIP(hipGetLastError());
+        std::vector<int64_t> begin_deg((size_t)nb * 2);
+        HVS_HIP(hipMemcpyAsync(begin_deg.data(), d_tmp.p, (size_t)nb * 16, hipMemcpyDeviceToHost, st));
+        HVS_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> seg_begin;
+        std::vector<int32_t> seg_len, row_seg((size_t)nb + 1);
+        for (int64_t r = 0; r < nb; ++r) {
+            row_seg[(size_t)r] = (int32_t)seg_begin.size();
+            for (int64_t off = 0; off < begin_deg[(size_t)(nb + r)]; off += BIG_SEGMENT) {
+                const int64_t left = begin_deg[(size_t)(nb + r)] - off;
+                seg_begin.push_back(begin_deg[(size_t)r] + off);
+                seg_len.push_back((int32_t)(left < BIG_SEGMENT ? left : BIG_SEGMENT));
+            }
+        }
+        row_seg[(size_t)nb] = (int32_t)seg_begin.size();
+        g->n_segs = (int64_t)seg_begin.size();
+        HVS_HIP(hipMalloc((void **)&g->seg_begin, (size_t)g->n_segs * 8));
+        HVS_HIP(hipMalloc((void **)&g->seg_len, (size_t)g->n_segs * 4));
+        HVS_HIP(hipMalloc((void **)&g->seg_sum, (size_t)g->n_segs * 8));
+        HVS_HIP(hipMalloc((void **)&g->row_seg, (size_t)(nb + 1) * 4));
+        HVS_HIP(hipMemcpyAsync(g->seg_begin, seg_begin.data(), (size_t)g->n_segs * 8, hipMemcpyHostToDevice, st));
+        HVS_HIP(hipMemcpyAsync(g->seg_len, seg_len.data(), (size_t)g->n_segs * 4, hipMemcpyHostToDevice, st));
+        HVS_HIP(hipMemcpyAsync(g->row_seg, row_seg.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+        HVS_HIP(hipStreamSynchronize(st));  // the host vectors go out of scope
     }
     unsigned long long dangling = 0;
     HVS_HIP(hipMemcpyAsync(&dangling, d_dangling, 8, hipMemcpyDeviceToHost, st));
@@ -453,7 +496,7 @@ static int graph_build(hvs_graph *g, const int32_t *src, const int32_t *dst, int
     HVS_HIP(hipMalloc((void **)&g->partials, (size_t)(2 * total_blocks + 2) * 8));
     HVS_HIP(hipMalloc((void **)&g->scal, 16));
     HVS_HIP(hipMalloc((void **)&g->state, 8));
-    HVS_HIP(hipMalloc((void **)&g->hist, (TOP_BINS + 2) * 4));
+    HVS_HIP(hipMalloc((void **)&g->hist, (TOP_BINS + 1) * 4));
     return 0;
 }
 
@@ -572,7 +615,8 @@ extern "C" int hvs_graph_pagerank(hvs_graph *g, const int32_t *seed_nodes, const
     int it = 0;
     while (it < max_iter && !state[0]) {
         // iterations are queued in batches; once the flag is set the remaining kernels of a batch return at once
-        const int batch = (max_iter - it) < 8 ? (max_iter - it) : 8;
+        int batch = it < 2 ? 2 : (it < 8 ? it : 8);  // 2, 2, 4, 8, 8, ...: big graphs meet the N-scaled bound after one or two
+        if (batch > max_iter - it) batch = max_iter - it;
         for (int b = 0; b < batch; ++b, ++it) {
             p.x_in = g->x[it & 1];
             p.y_in = g->y[it & 1];
@@ -580,8 +624,11 @@ extern "C" int hvs_graph_pagerank(hvs_graph *g, const int32_t *seed_nodes, const
             p.y_out = g->y[(it + 1) & 1];
             if (g->blocks[0]) ppr_rows_kernel<SMALL_LPR><<<g->blocks[0], GRAPH_THREADS, 0, st>>>(p, g->rows[0], g->n_rows[0], 0);
             if (g->blocks[1]) ppr_rows_kernel<64><<<g->blocks[1], GRAPH_THREADS, 0, st>>>(p, g->rows[1], g->n_rows[1], g->blocks[0]);
-            if (g->blocks[2])
-                ppr_big_rows_kernel<<<g->blocks[2], BIG_THREADS, 0, st>>>(p, g->rows[2], g->n_rows[2], g->blocks[0] + g->blocks[1]);
+            if (g->blocks[2]) {
+                ppr_big_segments_kernel<<<(int)g->n_segs, GRAPH_THREADS, 0, st>>>(p, g->seg_begin, g->seg_len, g->seg_sum);
+                ppr_big_finish_kernel<<<g->blocks[2], GRAPH_THREADS, 0, st>>>(p, g->rows[2], g->n_rows[2], g->row_seg, g->seg_sum,
+                                                                             g->blocks[0] + g->blocks[1]);
+            }
             ppr_fold_kernel<<<1, GRAPH_THREADS, 0, st>>>(g->partials, total_blocks, g->scal, g->state, (double)g->n * tol);
         }
         HVS_HIP(hipGetLastError());
@@ -621,15 +668,19 @@ extern "C" int hvs_graph_top_chunks(hvs_graph *g, int k, int32_t *out_nodes, dou
     hipStream_t st = g->stream;
     const double *x = g->x[g->result];
     // 1. histogram of sign+exponent over the chunk nodes -> the lowest bin that still has to be looked at
-    HVS_HIP(hipMemsetAsync(g->hist, 0, (TOP_BINS + 2) * 4, st));
+    HVS_HIP(hipMemsetAsync(g->hist, 0, (TOP_BINS + 1) * 4, st));
     top_hist_kernel<<<blocks_for(g->n, GRAPH_THREADS * 8), GRAPH_THREADS, 0, st>>>(x, g->chunk_mask, g->n, g->hist);
-    top_bin_kernel<<<1, 64, 0, st>>>(g->hist, k);
     HVS_HIP(hipGetLastError());
-    std::vector<uint32_t> hist(TOP_BINS + 2);
-    HVS_HIP(hipMemcpyAsync(hist.data(), g->hist, (TOP_BINS + 2) * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> hist(TOP_BINS);
+    HVS_HIP(hipMemcpyAsync(hist.data(), g->hist, TOP_BINS * 4, hipMemcpyDeviceToHost, st));
     HVS_HIP(hipStreamSynchronize(st));
+    // the lowest bin b such that bins b.. hold at least k chunk nodes (bin 0 if there are fewer)
     uint64_t cand = 0;
-    for (uint32_t b = hist[TOP_BINS]; b < TOP_BINS; ++b) cand += hist[b];
+    uint32_t bin = TOP_BINS - 1;
+    for (;; --bin) {
+        cand += hist[bin];
+        if (cand >= (uint64_t)k || bin == 0) break;
+    }
     if (cand == 0) {
         *out_count = 0;
         return 0;
@@ -648,7 +699,8 @@ extern "C" int hvs_graph_top_chunks(hvs_graph *g, int k, int32_t *out_nodes, dou
     char *base = (char *)w;
     uint32_t *n0 = (uint32_t *)(base + o_n0), *n1 = (uint32_t *)(base + o_n1);
     uint64_t *k0 = (uint64_t *)(base + o_k0), *k1 = (uint64_t *)(base + o_k1);
-    top_collect_kernel<<<blocks_for(g->n, GRAPH_THREADS * 8), GRAPH_THREADS, 0, st>>>(x, g->chunk_mask, g->n, g->hist, n0, k0, (uint32_t)cand);
+    top_collect_kernel<<<blocks_for(g->n, GRAPH_THREADS * 8), GRAPH_THREADS, 0, st>>>(x, g->chunk_mask, g->n, bin, g->hist + TOP_BINS, n0, k0,
+                                                                                      (uint32_t)cand);
     HVS_HIP(hipGetLastError());
     HVS_HIP(rocprim::radix_sort_pairs(base + o_t, sort1, n0, n1, k0, k1, (size_t)cand, 0, 32, st));
     HVS_HIP(rocprim::radix_sort_pairs_desc(base + o_t, sort2, k1, k0, n1, n0, (size_t)cand, 0, 64, st));
