@@ -27,7 +27,7 @@
 #define GRAPH_THREADS 256
 #define GRAPH_MAX_BLOCKS 2048
 #define SMALL_LPR 8
-#define SMALL_MAX_DEG 16
+#define SMALL_MAX_DEG 16  // = 2 * SMALL_LPR: ppr_small_rows_kernel reads at most two entries per lane
 #define MID_MAX_DEG 2048
 #define BIG_SEGMENT 8192
 #define TOP_BINS 4096  // sign + exponent of a double
@@ -210,6 +210,51 @@ __global__ void __launch_bounds__(GRAPH_THREADS) ppr_rows_kernel(PprParams p, co
         }
         sum = wave_sum(sum, LPR);
         if (sub == 0 && j >= 0) finish_row(p, j, sum, dang_in, err, dang);
+    }
+    block_partials<GRAPH_THREADS>(err, dang, p, slot_base + blockIdx.x);
+}
+
+// rows of at most SMALL_MAX_DEG = 2 * SMALL_LPR neighbours: a group of SMALL_LPR lanes works on SMALL_ROWS rows at a time
+// so that the four dependent loads of a row (row number, row_ptr, column, score) overlap across rows
+#define SMALL_ROWS 4
+__global__ void __launch_bounds__(GRAPH_THREADS) ppr_small_rows_kernel(PprParams p, const int32_t *__restrict__ rows, int64_t n_rows,
+                                                                       int slot_base) {
+    if (p.state[0]) return;
+    const int sub = threadIdx.x & (SMALL_LPR - 1);
+    const int64_t group = (blockIdx.x * (int64_t)GRAPH_THREADS + threadIdx.x) / SMALL_LPR;
+    const int64_t n_groups = (int64_t)gridDim.x * GRAPH_THREADS / SMALL_LPR;
+    const double dang_in = p.scal[1];
+    double err = 0.0, dang = 0.0;
+    for (int64_t base = 0; base < n_rows; base += n_groups * SMALL_ROWS) {
+        int64_t j[SMALL_ROWS], b[SMALL_ROWS], e[SMALL_ROWS];
+        int32_t c0[SMALL_ROWS], c1[SMALL_ROWS];
+        double sum[SMALL_ROWS];
+#pragma unroll
+        for (int q = 0; q < SMALL_ROWS; ++q) {
+            const int64_t r = base + group * SMALL_ROWS + q;
+            j[q] = r < n_rows ? rows[r] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < SMALL_ROWS; ++q) {
+            b[q] = j[q] >= 0 ? p.row_ptr[j[q]] : 0;
+            e[q] = j[q] >= 0 ? p.row_ptr[j[q] + 1] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < SMALL_ROWS; ++q) {
+            c0[q] = b[q] + sub < e[q] ? p.col[b[q] + sub] : -1;
+            c1[q] = b[q] + sub + SMALL_LPR < e[q] ? p.col[b[q] + sub + SMALL_LPR] : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < SMALL_ROWS; ++q) {
+            const double v0 = c0[q] >= 0 ? p.y_in[c0[q]] : 0.0;
+            const double v1 = c1[q] >= 0 ? p.y_in[c1[q]] : 0.0;
+            sum[q] = v0 + v1;
+        }
+#pragma unroll
+        for (int q = 0; q < SMALL_ROWS; ++q) {
+            const double total = wave_sum(sum[q], SMALL_LPR);
+            if (sub == 0 && j[q] >= 0) finish_row(p, j[q], total, dang_in, err, dang);
+        }
     }
     block_partials<GRAPH_THREADS>(err, dang, p, slot_base + blockIdx.x);
 }
@@ -622,7 +667,7 @@ extern "C" int hvs_graph_pagerank(hvs_graph *g, const int32_t *seed_nodes, const
             p.y_in = g->y[it & 1];
             p.x_out = g->x[(it + 1) & 1];
             p.y_out = g->y[(it + 1) & 1];
-            if (g->blocks[0]) ppr_rows_kernel<SMALL_LPR><<<g->blocks[0], GRAPH_THREADS, 0, st>>>(p, g->rows[0], g->n_rows[0], 0);
+            if (g->blocks[0]) ppr_small_rows_kernel<<<g->blocks[0], GRAPH_THREADS, 0, st>>>(p, g->rows[0], g->n_rows[0], 0);
             if (g->blocks[1]) ppr_rows_kernel<64><<<g->blocks[1], GRAPH_THREADS, 0, st>>>(p, g->rows[1], g->n_rows[1], g->blocks[0]);
             if (g->blocks[2]) {
                 ppr_big_segments_kernel<<<(int)g->n_segs, GRAPH_THREADS, 0, st>>>(p, g->seg_begin, g->seg_len, g->seg_sum);
