@@ -46,6 +46,8 @@ struct SearchParams {
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
     unsigned long long *prof;  // timing experiments only: per-phase cycle sums of wave 0 lanes (HVS_DBG & 512)
     const uint32_t *remap;  // optional: X holds a compacted copy; remap[r] = row position of its row r in the index
+    int split_steps;  // 0: plain operands.  > 0: both operands hold rows [hi slab | lo slab] of split_steps k-steps each
+                      // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
                     // 512 per-phase cycle counts printed to stderr
 };
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles<T>(srcA, srcB, stages, 0, wave);
+        dma_tiles<T>(srcA, srcB, stages, koff_plain(0), wave);
     }
     __syncthreads();
 
@@ -435,8 +437,14 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void mfma_search_kerne
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
         if (nks_next == 0 && g + 1 < total_steps) init_b(ntile);
         if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
+        KOff next_off = koff_plain(nks_next);
+        if (p.split_steps) {  // slab pairs (A, X) of the three products: (hi, hi), (hi, lo), (lo, hi)
+            const int slab = nks_next >= 2 * p.split_steps ? 2 : (nks_next >= p.split_steps ? 1 : 0), w = nks_next - slab * p.split_steps;
+            next_off.a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
+            next_off.b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
+        }
         compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
-                            nks_next, wave);
+                            next_off, wave);
         const bool tile_end = ks == p.nks - 1;
         const bool prof = tile_end && (p.dbg & 512);
         unsigned long long c1 = 0, c2 = 0, c3 = 0;
@@ -533,16 +541,20 @@ static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p
 
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
-                    int64_t *d_ids, int32_t *d_count) {
+                    int64_t *d_ids, int32_t *d_count, int split_mode) {
     const int pf = padded_fold(fold);
     const int nA = nq * pf;
     const int esz = idx->elem_size;
-    const int ld_bytes = idx->ld * esz;
-    const int lda_bytes = (ld_bytes + KB - 1) / KB * KB;
+    int ld_bytes = idx->ld * esz;
+    int lda_bytes = (ld_bytes + KB - 1) / KB * KB;
     const int lda = lda_bytes / esz;
+    // fp32 rows on the 16-bit pipe: both operands as [hi | lo] fp16 slabs (hvs_split.hip)
+    const int ld16 = (idx->dim + 63) / 64 * 64;
+    const size_t a_split_bytes = idx->dtype == HVS_F32 ? (((size_t)nA * ld16 * 4 + 255) & ~(size_t)255) + (((size_t)nA * 4 + 255) & ~(size_t)255) : 0;
     void *a_ws = nullptr;
     const size_t a_bytes = ((size_t)nA * lda_bytes + 255) & ~(size_t)255;
-    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + (size_t)nA * 4, &a_ws));
+    const size_t a_inv_bytes = ((size_t)nA * 4 + 255) & ~(size_t)255;
+    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + a_split_bytes, &a_ws));
     float *A_inv = (float *)((char *)a_ws + a_bytes);
     if (idx->dtype == HVS_F32)
         build_a_kernel<float><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (float *)a_ws, A_inv, fold, pf, idx->ld, lda);
@@ -599,14 +611,33 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
             p.row_end = row_end = n_live;
         }
     }
+    int kdt = idx->dtype;  // element type the kernel contracts in
+    if (idx->dtype == HVS_F32 && !p.remap && split_mode != 0 && !getenv("HVS_NO_SPLIT") &&
+        (split_mode == 1 || nA >= 64 || (idx->split && idx->split_n == idx->n))) {
+        bool ok = false;
+        HVS_TRY(hvs_split_ensure(idx, &ok));
+        if (ok) {
+            char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
+            float *a_split_inv = (float *)(a_split + (((size_t)nA * ld16 * 4 + 255) & ~(size_t)255));
+            HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, nA, lda, lda, ld16, a_split, a_split_inv));
+            kdt = HVS_F16;
+            p.A = a_split;
+            p.q_inv = a_split_inv;
+            p.lda_bytes = lda_bytes = ld16 * 4;
+            p.X = idx->split;
+            p.inv_norm = idx->split_inv;
+            ld_bytes = ld16 * 4;
+            p.split_steps = ld16 * 2 / KB;
+        }
+    }
     p.ld_bytes = ld_bytes;
-    p.nks = lda_bytes / KB;
+    p.nks = p.split_steps ? 3 * p.split_steps : lda_bytes / KB;
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
     // tile shape: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
-    bool big = idx->dtype != HVS_F32 && nA > Tile128::BM;
-    if (const char *e = getenv("HVS_TILE")) big = idx->dtype != HVS_F32 && atoi(e) == 256;
+    bool big = kdt != HVS_F32 && nA > Tile128::BM;
+    if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
     const int bm = big ? Tile256::BM : Tile128::BM, bn = big ? Tile256::BN : Tile128::BN;
     const int cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: the survivors of one more tile always fit
     p.cap = cap;
@@ -641,9 +672,9 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.overflow = overflow;
 
     HVS_TRY(hvs_prof_begin(idx));
-    if (idx->dtype == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, p)));
-    else if (idx->dtype == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, p)));
-    else if (idx->dtype == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, p)));
+    if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, p)));
+    else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, p)));
+    else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, p)));
     else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128>(pf, grid, idx->stream, p)));
     else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, p)));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
@@ -656,7 +687,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (p.dbg & 512) {
         unsigned long long h_prof[4] = {0, 0, 0, 0};
         HVS_HIP(hipMemcpy(h_prof, p.prof, sizeof(h_prof), hipMemcpyDeviceToHost));
-        const double waves = (double)grid * (idx->dtype != HVS_F32 && big ? Tile256::NW : Tile128::NW);
+        const double waves = (double)grid * (kdt != HVS_F32 && big ? Tile256::NW : Tile128::NW);
         fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f\n",
                 h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
     }

@@ -77,30 +77,37 @@ __device__ __forceinline__ void tile_src_init(TileSrcT<T::DMA_N> &t, const void 
     for (int i = 0; i < T::DMA_N; i++) t.voff[i] = dma_src_offset(tid, i, pitch_bytes, rows_valid - 1, T::GT);
 }
 
-// One LDS-DMA instruction of k-step `step`: j in [0, 2 DMA_N): even j -> A piece j/2, odd j -> X piece j/2.
+// Where the 128-byte k-slice of one k-step starts inside a row of each operand (bytes).  Plain operands:
+// both = step * KB.  Split operands (see KSplit) read different slabs of their rows in the same step.
+struct KOff {
+    int a, b;
+};
+__device__ __forceinline__ KOff koff_plain(int step) { return KOff{step * KB, step * KB}; }
+
+// One LDS-DMA instruction of a k-step: j in [0, 2 DMA_N): even j -> A piece j/2, odd j -> X piece j/2.
 template <class T = Tile128>
-__device__ __forceinline__ void dma_piece(const TileSrcT<T::DMA_N> &a, const TileSrcT<T::DMA_N> &b, char *stage, int step,
+__device__ __forceinline__ void dma_piece(const TileSrcT<T::DMA_N> &a, const TileSrcT<T::DMA_N> &b, char *stage, KOff off,
                                           int wave, int j) {
     const int i = j >> 1;
     char *d = stage + (T::GT * i + wave * 64) * 16 + ((j & 1) ? T::BM * KB : 0);
     const TileSrcT<T::DMA_N> &t = (j & 1) ? b : a;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_void *)d, 16, t.voff[i], step * KB, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rsrc, (lds_void *)d, 16, t.voff[i], (j & 1) ? off.b : off.a, 0, 0);
 }
 
 // Issue all LDS-DMA instructions of one k-step into `stage` (prologue use).
 template <class T = Tile128>
-__device__ __forceinline__ void dma_tiles(const TileSrcT<T::DMA_N> &a, const TileSrcT<T::DMA_N> &b, char *stage, int step,
+__device__ __forceinline__ void dma_tiles(const TileSrcT<T::DMA_N> &a, const TileSrcT<T::DMA_N> &b, char *stage, KOff off,
                                           int wave) {
 #pragma unroll
-    for (int j = 0; j < 2 * T::DMA_N; j++) dma_piece<T>(a, b, stage, step, wave, j);
+    for (int j = 0; j < 2 * T::DMA_N; j++) dma_piece<T>(a, b, stage, off, wave, j);
 }
 
 // acc[mt][nt] += A(MT*32 rows x 128 B) * X(NT*32 rows x 128 B)^T for this wave's sub-tile: 16 MT NT MFMAs
-// for fp32 rows, 4 MT NT for 16-bit rows.  The 2 DMA_N LDS-DMA pieces of k-step `next_step` are issued
+// for fp32 rows, 4 MT NT for 16-bit rows.  The 2 DMA_N LDS-DMA pieces of the next k-step (at `next_off`) are issued
 // into `next_stage` one at a time between groups of MFMAs, so that each piece's issue cost hides under
 // the execution of the MFMAs before it instead of stalling the wave in one burst.  They are issued
 // unconditionally (no branch in the loop): after the last k-step of a block the caller passes a valid
-// (next_step, source) pair again and the fetched stage is simply never read.
+// (offset, source) pair again and the fetched stage is simply never read.
 // Fragment addressing: lane (r = lane & 31, h = lane >> 5) reads the 16 bytes of k-chunk 2 s + h of its
 // row; for fp32 those 4 floats feed MFMA steps j = 0..3 of "octet" s (lane half h supplies k = 8 s + 4 h + j
 // to both operands, so the products pair up); for 16-bit types the 8 elements are exactly the
@@ -113,7 +120,7 @@ template <int DT> __device__ __forceinline__ f32x16 mfma16(const f32x4 &a, const
 template <int DT, class T = Tile128>
 __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const char *stage, int wm, int wn, int lane,
                                              const TileSrcT<T::DMA_N> &sa, const TileSrcT<T::DMA_N> &sb, char *next_stage,
-                                             int next_step, int wave) {
+                                             KOff next_off, int wave) {
     constexpr int MT = T::MT, NT = T::NT, PIECES = 2 * T::DMA_N;
     const int r = lane & 31;
     const int h = lane >> 5;
@@ -143,7 +150,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
                     for (int nt = 0; nt < NT; nt++)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mt][j], fb[nt][j], acc[mt][nt], 0, 0, 0);
                 if ((s * 4 + j) % EVERY == 0) {
-                    dma_piece<T>(sa, sb, next_stage, next_step, wave, (s * 4 + j) / EVERY);
+                    dma_piece<T>(sa, sb, next_stage, next_off, wave, (s * 4 + j) / EVERY);
                     __builtin_amdgcn_sched_barrier(0);  // pin the piece between these MFMA groups
                 }
             }
@@ -170,7 +177,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = 0; mt < HALF; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-            dma_piece<T>(sa, sb, next_stage, next_step, wave, 2 * s);
+            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s);
             __builtin_amdgcn_sched_barrier(0);
             if (s < 3) {
 #pragma unroll
@@ -183,7 +190,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = HALF; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-            dma_piece<T>(sa, sb, next_stage, next_step, wave, 2 * s + 1);
+            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

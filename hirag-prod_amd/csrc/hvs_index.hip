@@ -407,6 +407,8 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
     hipFree(idx->ids);
     hipFree(idx->groups);
     hipFree(idx->deleted);
+    hipFree(idx->split);
+    hipFree(idx->split_inv);
     for (auto &w : idx->ws) hipFree(w.ptr);
     hipEventDestroy(idx->ev0);
     hipEventDestroy(idx->ev1);
@@ -485,6 +487,7 @@ static int store_rows_device(hvs_index *idx, const void *src, int src_dtype, int
                              const int64_t *positions) {
     const int g = grid_for(n * (int64_t)idx->ld);
     hipStream_t s = idx->stream;
+    hvs_split_invalidate(idx, positions ? 0 : first);
     if (idx->dtype == HVS_F32) {
         HVS_REQUIRE(src_dtype == HVS_F32, "rows for an f32 index must be f32");
         store_rows_kernel<float, float><<<g, 256, 0, s>>>((const float *)src, (float *)idx->rows, n, idx->dim, idx->ld, first, positions);
@@ -702,6 +705,7 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
         idx->deleted = nullptr;
         idx->n_deleted = 0;
         idx->n = n_live;
+        hvs_split_invalidate(idx, 0);
         idx->cap = cap;
     } else if (renumber_ids && idx->n > 0) {
         fill_meta_kernel<<<grid_for(idx->n), 256, 0, idx->stream>>>(idx->ids, idx->groups, idx->n, 0, 0, 0, nullptr, idx->groups);

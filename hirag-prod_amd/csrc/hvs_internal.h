@@ -66,6 +66,13 @@ struct hvs_index {
     int64_t n = 0;
     int64_t cap = 0;
 
+    // fp32 indexes only: the rows as pairs of fp16 slabs for the 16-bit MFMA pipe (hvs_split.hip), built on the first
+    // batched search and extended after appends; rows [0, split_n) are current
+    void *split = nullptr;
+    float *split_inv = nullptr;
+    int64_t split_cap = 0, split_n = 0;
+    bool split_failed = false;  // device memory did not allow the copy
+
     hvs_workspace ws[7];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
                           // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search
 
@@ -98,6 +105,13 @@ int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, c
 // (distance, id) of the rows that pass lp (lp.dist set), ascending row position, first `capacity` of them; *total = all
 int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
                       int64_t *total);
+
+int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,
+                   void *dst, float *dst_inv);
+int hvs_split_ensure(hvs_index *idx, bool *ok);
+static inline void hvs_split_invalidate(hvs_index *idx, int64_t from_row) {
+    if (from_row < idx->split_n) idx->split_n = from_row < 0 ? 0 : from_row;
+}
 
 #define HVS_ROWS_SLACK 256  // zeroed bytes kept after the last row of a row matrix (see hvs_index_reserve)
 

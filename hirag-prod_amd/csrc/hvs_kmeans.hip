@@ -67,7 +67,7 @@ __global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles(srcA, srcB, stages, 0, wave);
+        dma_tiles(srcA, srcB, stages, koff_plain(0), wave);
     }
     __syncthreads();
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
         if (ks_next == 0 && g + 1 < total_steps) init_b(ntile);  // after the last step: re-fetch this tile's step 0 (unused)
         compute_step<HVS_F32>(acc, stages + cur * KT::STAGE_BYTES, wm, wn, lane, srcA, srcB,
-                              stages + (cur ^ 1) * KT::STAGE_BYTES, ks_next, wave);
+                              stages + (cur ^ 1) * KT::STAGE_BYTES, koff_plain(ks_next), wave);
 
         uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
         const bool last = ks == p.nks - 1;

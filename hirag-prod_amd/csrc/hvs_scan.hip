@@ -788,7 +788,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
 
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
-                    int64_t *d_ids, int32_t *d_count);
+                    int64_t *d_ids, int32_t *d_count, int split_mode);
 bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k);
 
 // ---- C ABI --------------------------------------------------------------------------------------
@@ -801,7 +801,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     HVS_REQUIRE(queries && out_dist && out_ids && out_count, "hvs_search: NULL argument");
     HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_search: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
     HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_search: k %d not in [1, %d]", k, HVS_MAX_K);
-    HVS_REQUIRE(algo == HVS_ALGO_AUTO || algo == HVS_ALGO_SCAN || algo == HVS_ALGO_MFMA, "hvs_search: unknown algo %d", algo);
+    HVS_REQUIRE(algo >= HVS_ALGO_AUTO && algo <= HVS_ALGO_MFMA_F32, "hvs_search: unknown algo %d", algo);
     if (row_end < 0 || row_end > idx->n) row_end = idx->n;
     if (row_begin < 0) row_begin = 0;
     if (row_begin > row_end) row_begin = row_end;
@@ -834,7 +834,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     }
 
     bool use_mfma = false;
-    if (algo == HVS_ALGO_MFMA) {
+    if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32) {
         HVS_REQUIRE(hvs_mfma_supported(idx, nq, fold, k), "hvs_search: the MFMA path does not support this shape (dtype %d, dim %d, fold %d, k %d)", idx->dtype, idx->dim, fold, k);
         use_mfma = true;
     } else if (algo == HVS_ALGO_AUTO) {
@@ -849,7 +849,9 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         use_mfma = false;
     }
     if (use_mfma)
-        HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
+        // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy for batches that repay building it
+        HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_MFMA ? 1 : 2)));
     else
         HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
 

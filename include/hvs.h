@@ -35,8 +35,15 @@ typedef struct hvs_index hvs_index;
 /* element type of the stored rows; schema/vector_config.py:8-11 (HALFVEC = fp16, VECTOR = fp32) */
 enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
 
-/* search algorithm selector */
-enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2 };
+/*
+ * search algorithm selector.  SCAN: streaming dot products, one pass over the rows per 8 (fp32) / 4-8
+ * (16-bit) embeddings.  MFMA: batched contraction on the matrix cores; for fp32 rows it runs on the
+ * 16-bit pipe over a split copy of the rows (two fp16 slabs per row, three products, fp32-grade
+ * scores; the copy doubles the table's device memory and is built on first use) and falls back to the
+ * fp32 MFMA kernel when memory does not allow the copy.  MFMA_F32: the fp32 MFMA kernel, no copy.
+ * AUTO picks by batch size.
+ */
+enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F32 = 3 };
 
 /* counters readable through hvs_profile_get */
 enum { HVS_PROF_SCAN = 0, HVS_PROF_MFMA_SEARCH = 1, HVS_PROF_KMEANS_ASSIGN = 2, HVS_PROF_KMEANS_UPDATE = 3,

@@ -46,6 +46,58 @@ def test_mfma_search_matches_oracle(hvs, n, d, dtype):
         d2, i2, c2 = idx.search(q[:8], k=k, algo="scan")
         np.testing.assert_array_equal(c2, cnt[:8])
         np.testing.assert_allclose(d2, dist[:8], atol=2e-6)
+        if dtype == "f32":  # "mfma" ran on the split copy (16-bit pipe); the fp32 MFMA kernel is the third route
+            d3, i3, c3 = idx.search(q, k=k, algo="mfma_f32")
+            _check_all(rows, q, 1, k, d3, i3, c3, label=f"mfma_f32 n={n} d={d} nq={nq} k={k}", storage=dtype)
+            np.testing.assert_array_equal(c3, cnt)
+            np.testing.assert_allclose(d3, dist, atol=2e-6)
+    idx.close()
+
+
+def test_split_copy_keeps_fp32_grade_scores(hvs):
+    """fp32 rows searched on the 16-bit matrix pipe through the [hi | lo] fp16 split: rows of every
+    magnitude, wide dynamic range inside a row, one-hot rows (the worst case for a dropped lo.lo term),
+    appended and overwritten rows; scores stay within 2e-6 of float64 and the ranking is the oracle's."""
+    rng = np.random.default_rng(2024)
+    n, d = 6000, 384
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[:500] *= np.exp(rng.uniform(-12, 0, (500, d))).astype(np.float32)      # six decades inside a row
+    rows[500:1000] *= np.float32(1e15)   # |row|^2 must stay inside fp32 for every route (and for the reference's float sums)
+    rows[1000:1500] *= np.float32(1e-15)
+    rows[1500:1600] = 0.0
+    rows[1500:1600][np.arange(100), rng.integers(0, d, 100)] = rng.uniform(0.3, 3.0, 100)  # one-hot rows
+    rows[1600] = 0.0
+    q = rng.standard_normal((96, d)).astype(np.float32)
+    q[1] = 0.0
+    q[1, 5] = 1.7   # a one-hot query against one-hot rows
+    q[2] = rows[700]  # exact hits at both ends of the magnitude range
+    q[3] = rows[1200]
+    q[4] *= np.float32(1e-15)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows[:4000])
+    dist, ids, cnt = idx.search(q, k=10, algo="mfma")          # builds the split copy of 4000 rows
+    _check_all(rows[:4000], q, 1, 10, dist, ids, cnt, label="split 4000")
+    idx.add(rows[4000:])                                        # the copy is extended, not rebuilt
+    new = rng.standard_normal((50, d)).astype(np.float32)
+    where = rng.permutation(n)[:50]
+    idx.update(where, new)                                      # overwritten rows invalidate it
+    rows[where] = new
+    for k in (1, 10, 100):
+        dist, ids, cnt = idx.search(q, k=k, algo="mfma")
+        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"split k={k}")
+        dm = parity.distance_matrix(rows, q, "f32")
+        for i in range(q.shape[0]):
+            c = int(cnt[i])
+            assert np.abs(dist[i, :c] - dm[i, ids[i, :c]]).max() < 2e-6, f"q={i}"
+        d3, i3, c3 = idx.search(q, k=k, algo="mfma_f32")
+        np.testing.assert_array_equal(c3, cnt)
+        np.testing.assert_allclose(d3, dist, atol=2e-6)
+    assert ids[2, 0] == 700 and dist[2, 0] < 2e-6 and ids[3, 0] == 1200 and dist[3, 0] < 2e-6
+    # fold over the split path, and the auto dispatch (>= 64 embeddings take it for fp32 rows)
+    dist, ids, cnt = idx.search(q, k=10, fold=3, algo="mfma")
+    _check_all(rows, q, 3, 10, dist, ids, cnt, label="split fold 3")
+    dist, ids, cnt = idx.search(q, k=10)
+    _check_all(rows, q, 1, 10, dist, ids, cnt, label="split auto")
     idx.close()
 
 
@@ -104,7 +156,8 @@ def test_filtered_batch_runs_over_compacted_rows(hvs, dtype):
     deleted = np.zeros(n, bool)
     deleted[np.arange(3, n, 640)] = True
     for gf, use_mask, rb, re_ in ((3, False, 0, n), (17, False, 5001, 29_000), (-1, True, 0, n), (3, True, 100, n), (99, False, 0, n)):
-        kw = dict(k=20, group_filter=gf, row_mask=mask if use_mask else None, row_begin=rb, row_end=re_, max_distance=1.2, algo="mfma")
+        kw = dict(k=20, group_filter=gf, row_mask=mask if use_mask else None, row_begin=rb, row_end=re_, max_distance=1.2,
+                  algo="mfma_f32")  # the dense copy is contracted by the kernel of the rows' own type; compare like with like
         dist, ids, cnt = idx.search(q, **kw)
         os.environ["HVS_NO_COMPACT"] = "1"
         try:
