@@ -10,6 +10,13 @@ work is fixed), every rank searches its shard with the fp32 MFMA kernel and an R
 the per-rank top-10 lists is merged on every rank.  The corpus is synthetic, generated in HBM by a
 counter-based generator before the timed region.
 
+The timed path computes in fp32 end to end (v_mfma_f32_32x32x2_f32, algo "mfma_f32").  The library's
+default for such batches is faster: it contracts a [hi | lo] fp16 split copy of the same fp32 rows
+on the 16-bit matrix pipe (three products per element, fp32 accumulation, scores within ~1e-8 of
+exact arithmetic).  That route is timed after the headline, on the same resident corpus and the
+same queries, and reported under "aux" -> "split_f16x3"; it is not the headline `value` because its
+products are formed from 16-bit operands.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (mfma_search_kernel) against
 the dense fp32 MFMA peak: algorithmic flops = 2 * queries * shard rows * dim per launch, divided
 by the kernel's mean duration measured with HIP events on the stream it runs on.  `cpu_baseline`
@@ -35,6 +42,7 @@ TOPK = 10
 SEED_CORPUS = 1234
 SEED_QUERY = 4321
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
 
 
@@ -130,7 +138,7 @@ def main():
     searcher = ShardedSearch.for_index(idx, None)
 
     def step():
-        return searcher.search(queries, TOPK, algo="mfma")
+        return searcher.search(queries, TOPK, algo="mfma_f32")
 
     for _ in range(args.warmup):
         step()
@@ -228,6 +236,45 @@ def main():
                 "scan_kernel_ms": sms / sn,
                 "scan_hbm_GBps": gbs,
                 "scan_hbm_frac": gbs / HBM_PEAK_GBS,
+            }
+
+    # the library's default route for this batch: fp32 rows as [hi | lo] fp16 slabs on the 16-bit matrix pipe
+    if not args.no_aux:
+        d_ref, i_ref, _ = out
+        searcher.search(queries, TOPK, algo="mfma")  # builds the split copy of the shard (once per table)
+        idx.profile(True)
+        idx.profile_reset()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d_s, i_s, _ = searcher.search(queries, TOPK, algo="mfma")
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e2 = time.perf_counter() - t0
+        kms, kn = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)
+        idx.profile(False)
+        if world > 1:
+            t = torch.tensor([e2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        if rank == 0:
+            per = kms / max(kn, 1)
+            alg = 2.0 * args.batch * (hi - lo) * DIM / (per * 1e-3) / 1e12
+            result["aux"]["split_f16x3"] = {
+                "qps": args.batch * args.steps / e2,
+                "ms_per_step": e2 / args.steps * 1e3,
+                "kernel": "mfma_search_kernel<f16, fold 1, Tile<256,256,2,4>> over [hi | lo] slabs, K = 3 x dim",
+                "ms_per_launch": per,
+                "algorithmic_TFLOPs": alg,
+                "executed_TFLOPs": 3.0 * alg,
+                "frac_of_f16_peak_algorithmic": alg / F16_MFMA_PEAK_TFLOPS,
+                "frac_of_f16_peak_executed": 3.0 * alg / F16_MFMA_PEAK_TFLOPS,
+                "max_abs_score_diff_vs_fp32_kernel": float((d_s - d_ref).abs().max().item()),
+                "ids_equal_to_fp32_kernel": float((i_s == i_ref).float().mean().item()),
+                "extra_device_memory_bytes": int((hi - lo) * ((DIM + 63) // 64 * 64) * 4),
             }
 
     if rank == 0:

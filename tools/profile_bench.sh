@@ -22,3 +22,7 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ
     -d "$OUT/sq" -o c --output-format csv -- \
     python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-aux > "$OUT/sq.json" 2> "$OUT/sq.log"
 echo "sq done"
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
+    -d "$OUT/sq_aux" -o c --output-format csv -- \
+    python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/sq_aux.json" 2> "$OUT/sq_aux.log"
+echo "sq_aux done"
