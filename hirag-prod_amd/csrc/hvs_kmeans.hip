@@ -1,39 +1,50 @@
-// k-means E-step (argmin over centroids) on the fp32 MFMA tile machinery; the M-step partial sums are in
+// k-means E-step (argmin over centroids) on the MFMA tile machinery; the M-step partial sums are in
 // hvs_kmeans_update.hip.
 //
 // assign[r] = argmin_j |x_r - c_j|^2 = argmin_j (|c_j|^2 - 2 x_r . c_j), lowest j on ties.
-// Blocks own a 128-centroid tile and stream the corpus (the blocks of the 8 XCD groups that share a
+// Blocks own a tile of centroids and stream the corpus (the blocks of the 8 XCD groups that share a
 // corpus split read the same tiles through one L2, so HBM sees every row once per iteration); each
 // block writes, per corpus row, the best (value, centroid) of its tile as one 64-bit key, and a
 // second kernel takes the minimum key over the centroid tiles.  No atomics, bit-reproducible.
+//
+// Two instantiations: fp32 operands on v_mfma_f32_32x32x2_f32 (128 x 128 tile), and the [hi | lo] fp16
+// split copies of rows and centroids (hvs_split.hip) on v_mfma_f32_32x32x16_f16 (256 x 256 tile, three
+// slab products per element), where the power-of-two scales of both operands are divided out of the
+// accumulator before the comparison.
 #include "hvs_gemm_tile.h"
 
-typedef Tile128 KT;  // block-tile shape of the assignment kernel
-
 struct AssignParams {
-    const float *C;        // centroids [K, ldc] (padded copy, ldc a multiple of BK, pad columns zero)
-    int ldc;
+    const void *C;         // centroids [K] rows of ldc_bytes (pad columns zero): fp32, or [hi | lo] halves
+    int ldc_bytes;
     const float *c_norm;   // [K] |c|^2
+    const float *c_iscale; // split operands: [K] 1 / scale of the centroid's split row; else NULL
     int K;
-    const float *X;        // corpus
+    const void *X;         // corpus rows of ld_bytes: fp32, or the split copy
+    const float *x_inv;    // split operands: inverse norms of the fp32 rows and of the split rows (their ratio is 1 / scale)
+    const float *x_split_inv;
     int64_t n;             // rows
-    int ld, nks;
+    int ld_bytes, nks;
+    int split_steps;       // 0 = plain; else k-steps per slab (the K loop runs 3 of them: hi.hi, hi.lo, lo.hi)
     int CT, S;             // centroid tiles, corpus splits
     int64_t T;             // corpus tiles
     uint64_t *best;        // [CT, n] keys
 };
 
-__global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p) {
+template <int DT, class T>
+__global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_kernel(AssignParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
+    static_assert(T::WM == 2, "the exchange below pairs wave row 1 with wave row 0");
+    constexpr int MT = T::MT, NT = T::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *stages = smem;
-    float *cn_lds = reinterpret_cast<float *>(smem + 2 * KT::STAGE_BYTES);           // [KT::BM]
-    uint64_t *xch = reinterpret_cast<uint64_t *>(cn_lds + KT::BM);                   // [2][64] keys (wm = 1 -> wm = 0)
+    float *cn_lds = reinterpret_cast<float *>(smem + 2 * T::STAGE_BYTES);        // [BM] |c|^2
+    float *cs_lds = cn_lds + T::BM;                                               // [BM] -2 / scale (split) or -2
+    uint64_t *xch = reinterpret_cast<uint64_t *>(cs_lds + T::BM);                // [WN][NT][32] keys (wm = 1 -> wm = 0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / T::WN, wn = wave % T::WN;
     const int h = lane >> 5;
 
     int ct, s;
@@ -46,59 +57,83 @@ __global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p
         s = blockIdx.x / p.CT;
     }
     const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
-    const int64_t a_row0 = (int64_t)ct * KT::BM;
-    for (int i = tid; i < KT::BM; i += KT::GT) {
+    const int64_t a_row0 = (int64_t)ct * T::BM;
+    for (int i = tid; i < T::BM; i += T::GT) {
         const int64_t c = a_row0 + i;
         cn_lds[i] = c < p.K ? p.c_norm[c] : __builtin_inff();  // padding centroids never win
+        cs_lds[i] = c < p.K && p.c_iscale ? -2.0f * p.c_iscale[c] : -2.0f;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
     zero_acc(acc);
     const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
-    TileSrc srcA, srcB;
+    TileSrcT<T::DMA_N> srcA, srcB;
     {
         const int64_t a_valid = p.K - a_row0;
-        tile_src_init(srcA, p.C, a_row0, a_valid < KT::BM ? (int)a_valid : KT::BM, p.ldc * 4, tid);
+        tile_src_init<T>(srcA, p.C, a_row0, a_valid < T::BM ? (int)a_valid : T::BM, p.ldc_bytes, tid);
     }
     auto init_b = [&](int64_t tile) {
-        const int64_t r0 = tile * KT::BN;
+        const int64_t r0 = tile * T::BN;
         const int64_t valid = p.n - r0;
-        tile_src_init(srcB, p.X, r0, valid < KT::BN ? (int)valid : KT::BN, p.ld * 4, tid);
+        tile_src_init<T>(srcB, p.X, r0, valid < T::BN ? (int)valid : T::BN, p.ld_bytes, tid);
     };
     if (total_steps > 0) {
         init_b(tile_lo);
-        dma_tiles(srcA, srcB, stages, koff_plain(0), wave);
+        dma_tiles<T>(srcA, srcB, stages, koff_plain(0), wave);
     }
     __syncthreads();
 
     int64_t tile = tile_lo;
     int ks = 0;
+    float x_is[NT];  // split operands: 1 / scale of this lane's rows
     for (int64_t g = 0; g < total_steps; g++) {
         const int cur = (int)(g & 1);
         int ks_next = ks + 1;
         int64_t ntile = tile;
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
         if (ks_next == 0 && g + 1 < total_steps) init_b(ntile);  // after the last step: re-fetch this tile's step 0 (unused)
-        compute_step<HVS_F32>(acc, stages + cur * KT::STAGE_BYTES, wm, wn, lane, srcA, srcB,
-                              stages + (cur ^ 1) * KT::STAGE_BYTES, koff_plain(ks_next), wave);
+        if (ks == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                x_is[nt] = 1.0f;
+                if (p.split_steps) {
+                    const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
+                    if (row < p.n) {
+                        const float inv = p.x_inv[row];
+                        x_is[nt] = inv < __builtin_inff() ? p.x_split_inv[row] / inv : 1.0f;  // exact: the ratio is a power of two
+                    }
+                }
+            }
+        }
+        KOff next_off = koff_plain(ks_next);
+        if (p.split_steps) {
+            const int slab = ks_next >= 2 * p.split_steps ? 2 : (ks_next >= p.split_steps ? 1 : 0), w = ks_next - slab * p.split_steps;
+            next_off.a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
+            next_off.b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
+        }
+        compute_step<DT, T>(acc, stages + cur * T::STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * T::STAGE_BYTES,
+                            next_off, wave);
 
-        uint64_t bestk[2] = {HVS_KEY_EMPTY, HVS_KEY_EMPTY};
+        uint64_t bestk[NT];
         const bool last = ks == p.nks - 1;
         if (last) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
+            for (int nt = 0; nt < NT; nt++) {
                 // per lane: strict "<" over increasing centroid index keeps the lowest index on ties
                 float bv = __builtin_inff();
                 int bi = -1;
 #pragma unroll
-                for (int mt = 0; mt < 2; mt++)
+                for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++) {
-                        const int a_loc = wm * 64 + mt * 32 + 8 * gq + 4 * h;
+                        const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;
                         const f32x4 cn = *reinterpret_cast<const f32x4 *>(cn_lds + a_loc);
+                        const f32x4 cs = *reinterpret_cast<const f32x4 *>(cs_lds + a_loc);
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const float v = fmaf(-2.0f, acc[mt][nt][4 * gq + e], cn[e]);
+                            // |c|^2 - 2 x.c; with split operands the accumulator holds x.c times both scales
+                            const float v = DT == HVS_F32 ? fmaf(-2.0f, acc[mt][nt][4 * gq + e], cn[e])
+                                                          : fmaf(acc[mt][nt][4 * gq + e] * x_is[nt], cs[e], cn[e]);
                             const bool lt = v < bv;  // false for NaN
                             bv = lt ? v : bv;
                             bi = lt ? a_loc + e : bi;
@@ -113,8 +148,8 @@ __global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p
             }
             zero_acc(acc);
             if (wm == 1 && h == 0) {
-                xch[(wn * 2 + 0) * 32 + (lane & 31)] = bestk[0];
-                xch[(wn * 2 + 1) * 32 + (lane & 31)] = bestk[1];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) xch[(wn * NT + nt) * 32 + (lane & 31)] = bestk[nt];
             }
         }
 
@@ -122,10 +157,10 @@ __global__ __launch_bounds__(KT::GT, 2) void kmeans_assign_kernel(AssignParams p
 
         if (last && wm == 0 && h == 0) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++) {
-                const uint64_t o = xch[(wn * 2 + nt) * 32 + (lane & 31)];
+            for (int nt = 0; nt < NT; nt++) {
+                const uint64_t o = xch[(wn * NT + nt) * 32 + (lane & 31)];
                 const uint64_t b = o < bestk[nt] ? o : bestk[nt];
-                const int64_t row = tile * KT::BN + wn * 64 + nt * 32 + (lane & 31);
+                const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
                 if (row < p.n) p.best[(size_t)ct * p.n + row] = b;
             }
         }
@@ -169,7 +204,29 @@ __global__ void prep_centroids_kernel(const float *__restrict__ src, float *__re
 
 int hvs_kmeans_update(hvs_index *idx, const int32_t *d_assign, int64_t n, int K, float *d_sums, int64_t *d_counts);  // hvs_kmeans_update.hip
 
-static size_t assign_lds_bytes() { return (size_t)2 * KT::STAGE_BYTES + KT::BM * 4 + 2 * 64 * 8; }
+template <class T> static size_t assign_lds_bytes() { return (size_t)2 * T::STAGE_BYTES + T::BM * 8 + T::WN * T::NT * 32 * 8; }
+
+__global__ void fill_ones_kernel(float *dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = 1.0f;
+}
+
+template <int DT, class T> static int launch_assign(AssignParams &p, int64_t n, hipStream_t st) {
+    p.CT = (p.K + T::BM - 1) / T::BM;
+    p.T = (n + T::BN - 1) / T::BN;
+    int S = ((T::GT == 256 ? 512 : 256) + p.CT - 1) / p.CT;  // fill every block slot of the chip
+    S = (S + 7) / 8 * 8;
+    if ((int64_t)S > p.T) S = (int)p.T;
+    if (S >= 8) S = S / 8 * 8;
+    if (S < 1) S = 1;
+    p.S = S;
+    const size_t lds = assign_lds_bytes<T>();
+    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<DT, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    kmeans_assign_kernel<DT, T><<<p.CT * S, T::GT, lds, st>>>(p);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_centroids, int32_t *out_assign,
                                  float *out_sums, int64_t *out_counts, int on_device) {
@@ -187,10 +244,20 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     const int ldc = (ld + 31) / 32 * 32;
     hipStream_t st = idx->stream;
 
-    // workspace 0: padded centroids + norms (+ raw host copy); workspace 1: best keys; workspace 3: host staging
+    // the [hi | lo] fp16 copies of rows and centroids put the contraction on the 16-bit matrix pipe
+    bool split = false;
+    if (K >= 64 && !getenv("HVS_NO_SPLIT")) HVS_TRY(hvs_split_ensure(idx, &split));
+    const int ld16 = (dim + 63) / 64 * 64;
+
+    // workspace 0: padded centroids + norms (+ split centroids, their 1/scale, ones) (+ raw host copy);
+    // workspace 1: best keys; workspace 3: host staging
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t cpad_bytes = (size_t)K * ldc * 4;
-    const size_t norm_off = (cpad_bytes + 255) & ~(size_t)255;
-    const size_t raw_off = (norm_off + (size_t)K * 4 + 255) & ~(size_t)255;
+    const size_t norm_off = up(cpad_bytes);
+    const size_t csplit_off = up(norm_off + (size_t)K * 4);
+    const size_t cis_off = csplit_off + (split ? up((size_t)K * ld16 * 4) : 0);
+    const size_t ones_off = cis_off + (split ? up((size_t)K * 4) : 0);
+    const size_t raw_off = ones_off + (split ? up((size_t)K * 4) : 0);
     const size_t raw_bytes = on_device ? 0 : (size_t)K * dim * 4;
     void *ws0 = nullptr;
     HVS_TRY(hvs_ws_get(idx, 0, raw_off + raw_bytes, &ws0));
@@ -206,24 +273,35 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
 
     AssignParams p;
     memset(&p, 0, sizeof(p));
-    p.C = c_pad;
     p.c_norm = c_norm;
     p.K = K;
-    p.X = (const float *)idx->rows;
     p.n = n;
-    p.ld = ld;
-    p.ldc = ldc;
-    p.nks = ldc / 32;
-    p.CT = (K + KT::BM - 1) / KT::BM;
-    p.T = (n + KT::BN - 1) / KT::BN;
-    int S = (512 + p.CT - 1) / p.CT;
-    S = (S + 7) / 8 * 8;
-    if ((int64_t)S > p.T) S = (int)p.T;
-    if (S >= 8) S = S / 8 * 8;
-    if (S < 1) S = 1;
-    p.S = S;
+    if (split) {
+        float *c_is = (float *)((char *)ws0 + cis_off), *ones = (float *)((char *)ws0 + ones_off);
+        fill_ones_kernel<<<(K + 255) / 256, 256, 0, st>>>(ones, K);
+        HVS_HIP(hipGetLastError());
+        // "inverse norm" 1 in, 1 / scale out
+        HVS_TRY(hvs_split_rows(st, c_pad, ones, 0, K, ldc, ldc, ld16, (char *)ws0 + csplit_off, c_is));
+        p.C = (char *)ws0 + csplit_off;
+        p.ldc_bytes = ld16 * 4;
+        p.c_iscale = c_is;
+        p.X = idx->split;
+        p.x_inv = idx->inv_norm;
+        p.x_split_inv = idx->split_inv;
+        p.ld_bytes = ld16 * 4;
+        p.split_steps = ld16 * 2 / KB;
+        p.nks = 3 * p.split_steps;
+    } else {
+        p.C = c_pad;
+        p.ldc_bytes = ldc * 4;
+        p.X = idx->rows;
+        p.ld_bytes = ld * 4;
+        p.nks = ldc / 32;
+    }
+    const bool big = split && K > Tile128::BM;
+    const int bm = big ? Tile256::BM : Tile128::BM;
     void *best = nullptr;
-    HVS_TRY(hvs_ws_get(idx, 1, (size_t)p.CT * n * 8, &best));
+    HVS_TRY(hvs_ws_get(idx, 1, (size_t)((K + bm - 1) / bm) * n * 8, &best));
     p.best = (uint64_t *)best;
 
     int32_t *d_assign = out_assign;
@@ -241,11 +319,10 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         }
     }
 
-    const size_t lds = assign_lds_bytes();
-    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HVS_TRY(hvs_prof_begin(idx));
-    kmeans_assign_kernel<<<p.CT * S, KT::GT, lds, st>>>(p);
-    HVS_HIP(hipGetLastError());
+    if (!split) HVS_TRY((launch_assign<HVS_F32, Tile128>(p, n, st)));
+    else if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128>(p, n, st)));
+    else HVS_TRY((launch_assign<HVS_F16, Tile256>(p, n, st)));
     int rg = (int)((n + 255) / 256);
     if (rg > 256 * 8) rg = 256 * 8;
     kmeans_reduce_kernel<<<rg, 256, 0, st>>>(p.best, p.CT, n, idx->n_deleted > 0 ? idx->deleted : nullptr, d_assign);
