@@ -200,29 +200,37 @@ def test_mfma_auto_dispatch_and_synthetic(hvs):
     idx.close()
 
 
-@pytest.mark.parametrize("n,d,kc", [(5000, 64, 5), (3000, 100, 200), (4100, 1536, 300)])
-def test_kmeans_assign_matches_oracle(hvs, n, d, kc):
+@pytest.mark.parametrize("route", ["default", "fp32"])
+@pytest.mark.parametrize("n,d,kc", [(5000, 64, 5), (3500, 72, 100), (3000, 100, 200), (4100, 1536, 300)])
+def test_kmeans_assign_matches_oracle(hvs, n, d, kc, route, monkeypatch):
+    """From 64 centroids on the default route contracts the [hi | lo] fp16 split copies on the 16-bit
+    pipe (128-tile up to 128 centroids, 256-tile beyond); HVS_NO_SPLIT keeps the fp32 MFMA kernel."""
+    if route == "fp32":
+        monkeypatch.setenv("HVS_NO_SPLIT", "1")
     rng = np.random.default_rng(n + kc)
     x = rng.standard_normal((n, d)).astype(np.float32)
+    x[: n // 4] *= np.float32(300.0)   # rows of very different norms: every row has its own split scale
+    x[n // 4 : n // 2] *= np.float32(0.004)
     c = x[rng.choice(n, kc, replace=False)].copy()
     c[1] = c[0]  # duplicate centroid: ties go to the lower index
     idx = hvs.HvsIndex(d, "f32")
     idx.add(x)
     assign, sums, counts = idx.kmeans_assign(c)
     exp, margin = kmeans_oracle.assign(x, c)
-    scale = float(np.mean(np.sum(x.astype(np.float64) ** 2, axis=1)))
     # centroids 0 and 1 are identical: an exact tie, which must go to index 0 on the GPU as in numpy
     tie01 = exp == 0
     assert tie01.any() and not np.any(exp == 1)
     np.testing.assert_array_equal(assign[tie01], 0)
     assert not np.any(assign == 1)
-    safe = (margin > 1e-5 * scale) | tie01  # below this an fp32 dot product may legitimately flip the argmin
-    assert safe.mean() > 0.99
+    # below this an fp32 dot product may legitimately flip the argmin (the contending centroids are of the row's own size)
+    xn = np.sum(x.astype(np.float64) ** 2, axis=1)
+    safe = (margin > 1e-5 * xn) | tie01
+    assert safe.mean() > 0.85
     np.testing.assert_array_equal(assign[safe], exp[safe])
     # rows that are themselves centroids are assigned to them (distance 0)
     _, esums, ecounts = kmeans_oracle.update(x, assign, c)
     np.testing.assert_array_equal(counts, ecounts)
-    np.testing.assert_allclose(sums, esums, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(sums, esums, rtol=1e-4, atol=1e-3 * float(np.abs(esums).max()))
     # assignment only
     a2, s2, c2 = idx.kmeans_assign(c, want_sums=False)
     np.testing.assert_array_equal(a2, assign)
