@@ -570,14 +570,23 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.q_inv = A_inv;
     p.nA = nA;
     p.lda_bytes = lda_bytes;
-    p.X = idx->rows;
-    p.inv_norm = idx->inv_norm;
     p.groups = idx->groups;
     p.mask = d_mask;
     p.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
     p.group_filter = group_filter;
     p.row_begin = row_begin;
     p.row_end = row_end;
+
+    // fp32 rows on the 16-bit pipe: decided first, because a filtered search gathers from whichever copy is contracted
+    bool use_split = false;
+    if (idx->dtype == HVS_F32 && split_mode != 0 && !getenv("HVS_NO_SPLIT") &&
+        (split_mode == 1 || nA >= 64 || (idx->split && idx->split_n == idx->n)))
+        HVS_TRY(hvs_split_ensure(idx, &use_split));
+    const void *src_rows = use_split ? idx->split : idx->rows;
+    const float *src_inv = use_split ? idx->split_inv : idx->inv_norm;
+    if (use_split) ld_bytes = ld16 * 4;
+    p.X = src_rows;
+    p.inv_norm = src_inv;
 
     // A WHERE on the group code or a row bitmask: count the live rows and, when they are a minority,
     // contract over a dense copy of them (tombstones alone are sparse and stay in the epilogue): the
@@ -598,7 +607,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
             HVS_HIP(hipMemsetAsync(c_rows + copy_bytes, 0, HVS_ROWS_SLACK, idx->stream));  // see hvs_index_reserve
             if (n_live > 0) {
                 HVS_TRY(hvs_live_write(idx, lp, positions));
-                HVS_TRY(hvs_live_gather(idx, positions, n_live, c_rows, c_inv));
+                HVS_TRY(hvs_live_gather(idx, src_rows, src_inv, ld_bytes, positions, n_live, c_rows, c_inv));
             }
             p.X = c_rows;
             p.inv_norm = c_inv;
@@ -612,23 +621,15 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         }
     }
     int kdt = idx->dtype;  // element type the kernel contracts in
-    if (idx->dtype == HVS_F32 && !p.remap && split_mode != 0 && !getenv("HVS_NO_SPLIT") &&
-        (split_mode == 1 || nA >= 64 || (idx->split && idx->split_n == idx->n))) {
-        bool ok = false;
-        HVS_TRY(hvs_split_ensure(idx, &ok));
-        if (ok) {
-            char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
-            float *a_split_inv = (float *)(a_split + (((size_t)nA * ld16 * 4 + 255) & ~(size_t)255));
-            HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, nA, lda, lda, ld16, a_split, a_split_inv));
-            kdt = HVS_F16;
-            p.A = a_split;
-            p.q_inv = a_split_inv;
-            p.lda_bytes = lda_bytes = ld16 * 4;
-            p.X = idx->split;
-            p.inv_norm = idx->split_inv;
-            ld_bytes = ld16 * 4;
-            p.split_steps = ld16 * 2 / KB;
-        }
+    if (use_split) {
+        char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
+        float *a_split_inv = (float *)(a_split + (((size_t)nA * ld16 * 4 + 255) & ~(size_t)255));
+        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, nA, lda, lda, ld16, a_split, a_split_inv));
+        kdt = HVS_F16;
+        p.A = a_split;
+        p.q_inv = a_split_inv;
+        p.lda_bytes = lda_bytes = ld16 * 4;
+        p.split_steps = ld16 * 2 / KB;
     }
     p.ld_bytes = ld_bytes;
     p.nks = p.split_steps ? 3 * p.split_steps : lda_bytes / KB;

@@ -351,10 +351,11 @@ int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *position
     return 0;
 }
 
-int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv) {
+int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, int row_bytes, const uint32_t *positions,
+                    int64_t n_live, char *dst_rows, float *dst_inv) {
     if (n_live <= 0) return 0;
-    gather_live_kernel<<<(unsigned)((n_live + 3) / 4), 256, 0, idx->stream>>>((const char *)idx->rows, idx->inv_norm, positions,
-                                                                             n_live, idx->ld * idx->elem_size / 16, dst_rows, dst_inv);
+    gather_live_kernel<<<(unsigned)((n_live + 3) / 4), 256, 0, idx->stream>>>((const char *)src_rows, src_inv, positions, n_live,
+                                                                             row_bytes / 16, dst_rows, dst_inv);
     HVS_HIP(hipGetLastError());
     return 0;
 }
@@ -676,7 +677,7 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
             }
             if (n_live > 0) {
                 if ((rc = hvs_live_write(idx, lp, positions)) != 0) break;
-                if ((rc = hvs_live_gather(idx, positions, n_live, rows, inv)) != 0) break;
+                if ((rc = hvs_live_gather(idx, idx->rows, idx->inv_norm, idx->ld * idx->elem_size, positions, n_live, rows, inv)) != 0) break;
                 gather_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->ids, idx->groups, positions, n_live, ids, groups);
                 if (renumber_ids) fill_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(ids, groups, n_live, 0, 0, 0, nullptr, groups);
             }

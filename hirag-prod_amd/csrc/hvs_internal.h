@@ -101,7 +101,9 @@ struct hvs_live_params {
 };
 int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live);          // synchronises the stream
 int hvs_live_write(hvs_index *idx, const hvs_live_params &lp, uint32_t *positions);        // after hvs_live_count
-int hvs_live_gather(hvs_index *idx, const uint32_t *positions, int64_t n_live, char *dst_rows, float *dst_inv);
+// dst row i = row positions[i] of a row matrix with rows of row_bytes (a multiple of 16), with its inverse norm
+int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, int row_bytes, const uint32_t *positions,
+                    int64_t n_live, char *dst_rows, float *dst_inv);
 // (distance, id) of the rows that pass lp (lp.dist set), ascending row position, first `capacity` of them; *total = all
 int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
                       int64_t *total);

@@ -135,8 +135,8 @@ def test_mfma_fold_threshold_filters(hvs, fold, dtype):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_filtered_batch_runs_over_compacted_rows(hvs, dtype):
+@pytest.mark.parametrize("dtype,algo", [("f32", "mfma_f32"), ("f32", "mfma"), ("bf16", "mfma")])
+def test_filtered_batch_runs_over_compacted_rows(hvs, dtype, algo):
     """A selective filter makes the batched path contract over a dense copy of the live rows; the answer
     must be the one the in-epilogue filter gives (same keys, ties included) and the oracle's."""
     rng = np.random.default_rng(77)
@@ -157,7 +157,7 @@ def test_filtered_batch_runs_over_compacted_rows(hvs, dtype):
     deleted[np.arange(3, n, 640)] = True
     for gf, use_mask, rb, re_ in ((3, False, 0, n), (17, False, 5001, 29_000), (-1, True, 0, n), (3, True, 100, n), (99, False, 0, n)):
         kw = dict(k=20, group_filter=gf, row_mask=mask if use_mask else None, row_begin=rb, row_end=re_, max_distance=1.2,
-                  algo="mfma_f32")  # the dense copy is contracted by the kernel of the rows' own type; compare like with like
+                  algo=algo)  # fp32 rows: the fp32 MFMA kernel, or the split copy (the dense copy is then gathered from it)
         dist, ids, cnt = idx.search(q, **kw)
         os.environ["HVS_NO_COMPACT"] = "1"
         try:
