@@ -224,16 +224,24 @@ class HvsIndex:
             if mask.size < (len(self) + 31) // 32:
                 raise ValueError("row_mask has fewer bits than the index has rows")
         total = ctypes.c_int64(0)
+
+        def call(cap):
+            dist = np.empty((cap,), dtype=np.float32)
+            ids = np.empty((cap,), dtype=np.int64)
+            check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
+                                             row_begin, row_end, cap, _np_ptr(dist), _np_ptr(ids), ctypes.byref(total), 0))
+            return dist, ids
+
         with self._lock:
-            if capacity is None:  # size the outputs from a counting call
-                check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
-                                                 row_begin, row_end, 0, None, None, ctypes.byref(total), 0))
-                capacity = total.value
-            dist = np.empty((capacity,), dtype=np.float32)
-            ids = np.empty((capacity,), dtype=np.int64)
-            if capacity > 0:
-                check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
-                                                 row_begin, row_end, capacity, _np_ptr(dist), _np_ptr(ids), ctypes.byref(total), 0))
+            if capacity is None:  # most selections are small: one pass with room for 64k rows, a second only if they did not fit
+                capacity = 65536
+                dist, ids = call(capacity)
+                if total.value > capacity:
+                    capacity = total.value
+                    dist, ids = call(capacity)
+            else:
+                capacity = max(int(capacity), 0)  # 0: count only
+                dist, ids = call(capacity)
         m = min(capacity, total.value)
         return dist[:m], ids[:m], total.value
 
