@@ -30,6 +30,10 @@ def __getattr__(name):
         from . import graph_store
 
         return getattr(graph_store, name)
+    if name in ("ClusterFilter", "ward_labels"):
+        from . import cluster_filter
+
+        return getattr(cluster_filter, name)
     if name in ("ShardedSearch", "sharded_kmeans_step", "shard_range"):
         from . import sharded
 

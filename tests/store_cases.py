@@ -5,6 +5,7 @@ any for this path (it has none: its storage tests need a live PostgreSQL)."""
 import asyncio
 import hashlib
 import math
+from datetime import datetime
 
 import numpy as np
 
@@ -268,6 +269,26 @@ async def scenario_graph_and_fusion(store, storage):
     res = await FusionQueryService(store, reranker=Reverser()).query("ws1", "kb1", query, strategy="hybrid", topk=10, topn=3)
     assert [c["documentKey"] for c in res["chunks"]] == [n for n, _ in exp][::-1][:3]
     assert {c["documentKey"] for c in res["outliers"]} == set(chunk_recall["chunk_ids"]) - {c["documentKey"] for c in res["chunks"]}
+    # the clustering filter after PageRank: ward labels of the ranked chunks' stored vectors, latest timestamp per cluster
+    from hirag_prod_amd.cluster_filter import ClusterFilter, ward_labels
+
+    ranked = fused["pagerank"]
+    stamps = {r["documentKey"]: datetime(2024, 1, 1 + (i % 3)) for i, r in enumerate(ranked)}
+    for r in ranked:
+        r["extractedTimestamp"] = stamps[r["documentKey"]]
+    kept = await ClusterFilter(store)("ws1", "kb1", ranked)
+    feats = np.stack([po.round_storage(embed_text(r["text"]), storage).astype(np.float64) for r in ranked])
+    labels = ward_labels(feats, n_clusters=3)
+    want = []
+    for lab in dict.fromkeys(labels.tolist()):
+        members = [r for r, l in zip(ranked, labels) if l == lab]
+        top = max(stamps[m["documentKey"]] for m in members)
+        want.extend(m["documentKey"] for m in members if stamps[m["documentKey"]] == top)
+    assert [c["documentKey"] for c in kept] == want and 3 <= len(kept) < len(ranked)
+    assert await ClusterFilter(store)("ws1", "kb1", ranked[:2]) == ranked[:2]  # fewer chunks than clusters: unchanged
+    res = await FusionQueryService(store, cluster_filter=ClusterFilter(store)).query("ws1", "kb1", query, filter_by_clustering=True,
+                                                                                    strategy="pagerank", topk=10, topn=5)
+    assert 3 <= len(res["chunks"]) <= 10 and len(res["chunks"]) + len(res["outliers"]) >= len(chunk_recall["chunk_ids"])
     raw = await svc.query("ws1", "kb1", query, strategy="raw")
     assert raw["chunk_ids"] == chunk_recall["chunk_ids"]
     # no fact signal (no triplets in that workspace): the retrieval order comes back unchanged
