@@ -30,6 +30,10 @@ template <int BM_, int BN_, int WM_, int WN_> struct Tile {
 };
 typedef Tile<128, 128, 2, 2> Tile128;
 typedef Tile<256, 256, 2, 4> Tile256;
+//   Tile64:  64 x 64, 2 waves of 64 x 32, four blocks per CU.  For small batches on the 16-bit pipe: a block always
+//            contracts BM query rows, so up to 64 embeddings cost half the MFMA work of Tile128 and the search
+//            falls back onto the HBM stream.
+typedef Tile<64, 64, 1, 2> Tile64;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
