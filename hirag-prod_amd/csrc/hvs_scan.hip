@@ -841,7 +841,10 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         // Crossover measured on 1M x 1536: the scan takes 8 dot products per pass over the rows, the MFMA path
         // costs a whole 128-query tile whatever the count -- 3.3 ms for fp32 rows (two scan passes), but
         // only 0.65 ms for 16-bit rows, which is what the scan needs for four embeddings.
-        const int crossover = idx->dtype == HVS_F32 ? 16 : 6;
+        // With the split copy of an fp32 table in place its batches run on the 16-bit pipe too (6.5 ms against 8.9 ms
+        // for 8 queries on 4M x 1536).
+        const bool f32_pipe = idx->dtype == HVS_F32 && !(idx->split && idx->split_n == idx->n && !getenv("HVS_NO_SPLIT"));
+        const int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
         use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);
     }
     if (row_end == row_begin) {
