@@ -188,7 +188,7 @@ __device__ __forceinline__ void finish_row(const PprParams &p, int64_t j, double
     if (inv == 0.0) dang += xn;
 }
 
-// LPR lanes per row (LPR = 8: short rows; LPR = 64: one wave per row)
+// LPR lanes per row (used with LPR = 64: one wave per row of 17 .. 2048 neighbours)
 template <int LPR>
 __global__ void __launch_bounds__(GRAPH_THREADS) ppr_rows_kernel(PprParams p, const int32_t *__restrict__ rows, int64_t n_rows,
                                                                  int slot_base) {
