@@ -484,6 +484,246 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// single query tile: the corpus streams from HBM
+// ---------------------------------------------------------------------------------------------
+// With few query embeddings there is one query tile, every block streams its own slab of the corpus from HBM, and
+// the two-stage kernel above keeps one k-step in flight: a step then lasts one loaded-HBM latency.  This variant is
+// laid out for that regime: a narrow query tile (BM = 32 or 64 rows) against 256 corpus rows, so that most of a
+// stage is corpus, and a ring of NS stages whose fetches run NS - 1 k-steps ahead (explicit vmcnt waits instead of a
+// full fence at the step barrier).  4 waves of BM x 64, one block per CU.  16-bit operands only: 16-bit tables, and
+// the [hi | lo] split copy of fp32 tables (DUAL), for which a stage carries BOTH slabs of the query tile: the hi
+// slab of the corpus meets hi and lo of the queries in one step, the lo slab meets hi in another, so every corpus
+// byte is fetched once (the three-product order of the large-batch kernel would fetch the hi slab twice, and here
+// the corpus stream is the bound).
+template <int BM_, bool DUAL_> struct StreamTile {
+    static constexpr int BM = BM_, BN = 256, WM = 1, WN = 4;
+    static constexpr bool DUAL = DUAL_;
+    static constexpr int NW = 4, GT = 256;
+    static constexpr int MT = BM / 32, NT = 2;
+    static constexpr int A_IMAGES = DUAL ? 2 : 1;
+    static constexpr int STAGE_BYTES = (A_IMAGES * BM + BN) * KB;
+    static constexpr int NA = BM * KB / 16 / GT, NB = BN * KB / 16 / GT;  // LDS-DMA instructions per thread, image and k-step
+    static_assert(BM * KB / 16 % GT == 0, "whole pieces per thread");
+};
+
+// ring depth: as many stages as the 160 KB of LDS hold next to the per-query state, at most 4
+template <class T> __host__ __device__ constexpr int stream_stages() {
+    return T::STAGE_BYTES * 4 + T::BM * 16 <= 160 * 1024 - 1024 ? 4 : 3;
+}
+
+template <int N>
+__device__ __forceinline__ void stream_src_init(TileSrcT<N> &t, const void *base, int64_t row0, int rows_valid, int pitch_bytes, int tid,
+                                                int threads) {
+    const char *ptr = reinterpret_cast<const char *>(base) + row0 * pitch_bytes;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)ptr);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)ptr >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane(rows_valid * pitch_bytes);
+    t.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi << 32) | lo), 0, bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < N; i++) t.voff[i] = dma_src_offset(tid, i, pitch_bytes, rows_valid - 1, threads);
+}
+
+template <int DT, int FOLD, class T>
+__global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT, NS = stream_stages<T>();
+    constexpr int PIECES = T::A_IMAGES * T::NA + T::NB;
+    constexpr int X_IMAGE = T::A_IMAGES * BM * KB;  // the corpus image follows the query image(s)
+    static_assert(PIECES * (NS - 1) <= 63, "vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;
+    const int s = blockIdx.x;  // one query tile: the grid is the corpus splits
+    const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
+    BlockState b;
+    b.tau = reinterpret_cast<float *>(smem + NS * STAGE_BYTES);
+    b.cnt = reinterpret_cast<int *>(b.tau + BM);
+    b.qinv = reinterpret_cast<float *>(b.cnt + BM);
+    b.bound = b.qinv + BM;
+    b.my_cand = p.cand + (size_t)blockIdx.x * (BM / FOLD) * p.cap;
+    block_state_init<T>(p, b, 0, tid);
+
+    f32x16 acc[MT][NT];
+    float invn2[NT];
+    zero_acc(acc);
+    const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
+    TileSrcT<T::NA> srcA;
+    TileSrcT<T::NB> srcB;
+    stream_src_init<T::NA>(srcA, p.A, 0, p.nA < BM ? p.nA : BM, p.lda_bytes, tid, T::GT);
+    auto init_b = [&](int64_t tile) {
+        const int64_t r0 = p.row_begin + tile * BN;
+        const int64_t valid = p.row_end - r0;
+        stream_src_init<T::NB>(srcB, p.X, r0, valid < BN ? (int)valid : BN, p.ld_bytes, tid, T::GT);
+    };
+    // All LDS-DMA instructions of one k-step into a stage.  DUAL: steps [0, S) fetch (A hi, A lo | X hi), steps
+    // [S, 2 S) fetch (A hi, A hi again (unused) | X lo); the instruction count per step is constant, which the vmcnt
+    // arithmetic below relies on.
+    auto fetch = [&](char *stage, int ks) {
+        int off_a = ks * KB, off_a2 = ks * KB, off_b = ks * KB;
+        if (T::DUAL) {
+            const int second = ks >= p.split_steps ? 1 : 0, w = ks - second * p.split_steps;
+            off_a = w * KB;
+            off_a2 = second ? off_a : (p.split_steps + w) * KB;
+            off_b = (second * p.split_steps + w) * KB;
+        }
+#pragma unroll
+        for (int i = 0; i < T::NA; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + (T::GT * i + wave * 64) * 16), 16, srcA.voff[i], off_a, 0, 0);
+        if (T::DUAL) {
+#pragma unroll
+            for (int i = 0; i < T::NA; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + BM * KB + (T::GT * i + wave * 64) * 16), 16,
+                                                         srcA.voff[i], off_a2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < T::NB; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB.rsrc, (lds_void *)(stage + X_IMAGE + (T::GT * i + wave * 64) * 16), 16, srcB.voff[i],
+                                                     off_b, 0, 0);
+    };
+
+    // fetch cursor: the step whose fetch is issued next (runs NS - 1 steps ahead of the compute cursor)
+    int64_t f_tile = tile_lo;
+    int f_ks = 0;
+    int64_t f_step = 0;
+    auto fetch_next = [&](int slot) {
+        if (f_step < total_steps && f_ks == 0) init_b(f_tile);
+        // past the end the last valid step is fetched again into a stage nobody reads: keeps the instruction count
+        // per step (and with it the vmcnt arithmetic) constant
+        fetch(smem + slot * STAGE_BYTES, f_ks);
+        if (f_step < total_steps - 1) {
+            f_ks++;
+            if (f_ks == p.nks) { f_ks = 0; f_tile++; }
+        }
+        f_step++;
+    };
+    if (total_steps > 0) {
+#pragma unroll
+        for (int d = 0; d < NS - 1; d++) fetch_next(d);
+        // the first step's fetch is the oldest: everything issued after it may still be outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (NS - 2)) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the per-query state written above
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const int r = lane & 31, h = lane >> 5;
+    const int swz = lds_swz(r);
+    int64_t tile = tile_lo;
+    int ks = 0;
+    int slot = 0;
+    bool compact_due = false;
+    for (int64_t g = 0; g < total_steps; g++) {
+        // the stage read during the previous step is free: every wave has passed that step's barrier
+        int fslot = slot + NS - 1;
+        fslot = fslot >= NS ? fslot - NS : fslot;
+        fetch_next(fslot);
+        if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
+        {
+            const char *As = smem + slot * STAGE_BYTES + r * KB;
+            const char *Bs = smem + slot * STAGE_BYTES + X_IMAGE + (wn * (NT * 32) + r) * KB;
+            auto frag = [&](const char *base, int t, int kc) {
+                return *reinterpret_cast<const f32x4 *>(base + t * (32 * KB) + ((kc ^ swz) << 4));
+            };
+            const bool both = T::DUAL && ks < p.split_steps;  // the second query image holds the lo slab
+            f32x4 fa[2][MT], fa2[2][MT], fb[2][NT];
+#pragma unroll
+            for (int t = 0; t < MT; t++) {
+                fa[0][t] = frag(As, t, h);
+                if (T::DUAL) fa2[0][t] = frag(As + BM * KB, t, h);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) fb[0][t] = frag(Bs, t, h);
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                if (sl < 3) {  // next slice's fragments land while this slice's MFMAs run
+#pragma unroll
+                    for (int t = 0; t < MT; t++) {
+                        fa[(sl + 1) & 1][t] = frag(As, t, 2 * (sl + 1) + h);
+                        if (T::DUAL) fa2[(sl + 1) & 1][t] = frag(As + BM * KB, t, 2 * (sl + 1) + h);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; t++) fb[(sl + 1) & 1][t] = frag(Bs, t, 2 * (sl + 1) + h);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[sl & 1][mt], fb[sl & 1][nt], acc[mt][nt]);
+                if (both) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa2[sl & 1][mt], fb[sl & 1][nt], acc[mt][nt]);
+                }
+            }
+        }
+        const bool tile_end = ks == p.nks - 1;
+        if (tile_end) {
+            tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, 0, wn, lane);
+            zero_acc(acc);
+        }
+        // The next step's fetch (issued NS - 2 steps ago) has landed for this wave, then -- barrier -- for all of them.
+        // Vector memory operations retire in order, so allowing only the youngest fetches to be outstanding also
+        // covers what was issued before them.  The candidate keys a tile's epilogue stores are ranked one step
+        // later (compact_due): by then only the fetch issued after them may still be in flight, and the ring never
+        // drains.  A K loop of a single step has no later step before the next epilogue and drains instead.
+        if (p.nks == 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            compact_lists<FOLD, T>(p, b, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            if (compact_due) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES * (NS - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (compact_due) compact_lists<FOLD, T>(p, b, wave, lane);
+            compact_due = tile_end;
+        }
+        ks++;
+        if (ks == p.nks) { ks = 0; tile++; }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block
+    __syncthreads();
+    publish_lists<FOLD, T>(p, b, 0, s, wave, lane);
+#endif
+}
+
+template <class T> static size_t stream_lds_bytes() { return (size_t)stream_stages<T>() * T::STAGE_BYTES + T::BM * 16; }
+
+template <int DT, class T>
+static int launch_stream(int pf, int grid, hipStream_t st, const SearchParams &p) {
+    const size_t lds = stream_lds_bytes<T>();
+#define HVS_LAUNCH_STREAM(F)                                                                                         \
+    do {                                                                                                             \
+        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_stream_kernel<DT, F, T>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        mfma_stream_kernel<DT, F, T><<<grid, T::GT, lds, st>>>(p);                                                   \
+    } while (0)
+    if (pf == 1) HVS_LAUNCH_STREAM(1);
+    else if (pf == 2) HVS_LAUNCH_STREAM(2);
+    else HVS_LAUNCH_STREAM(4);
+#undef HVS_LAUNCH_STREAM
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int DT>
+static int launch_stream_bm(int bm, bool dual, int pf, int grid, hipStream_t st, const SearchParams &p) {
+    if (dual) {
+        if (bm == 32) return launch_stream<DT, StreamTile<32, true>>(pf, grid, st, p);
+        return launch_stream<DT, StreamTile<64, true>>(pf, grid, st, p);
+    }
+    if (bm == 32) return launch_stream<DT, StreamTile<32, false>>(pf, grid, st, p);
+    return launch_stream<DT, StreamTile<64, false>>(pf, grid, st, p);
+}
+
 #define HVS_COMPACT_MAX_BYTES ((size_t)16 << 30)  // largest dense copy a filtered search may make
 
 // ---------------------------------------------------------------------------------------------
@@ -636,6 +876,43 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
+    // one query tile of 16-bit operands and enough rows to keep every CU streaming: the ring kernel
+    bool stream = kdt != HVS_F32 && nA <= 64 && row_end - row_begin >= 256 * 256;
+    if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= 64 && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
+    if (stream) {
+        const int bm = nA <= 32 ? 32 : 64;
+        if (p.split_steps) p.nks = 2 * p.split_steps;  // (A hi, A lo | X hi) steps, then (A hi | X lo) steps
+        p.cap = CAND_MAX;
+        p.QT = 1;
+        p.T = (row_end - row_begin + 255) / 256;
+        p.S = (int)(p.T < 256 ? p.T : 256);
+        p.dbg = 0;
+        const int grid = p.S;
+        void *cand = nullptr, *bufB = nullptr;
+        const size_t cand_bytes = (size_t)grid * (bm / pf) * p.cap * 8;
+        const size_t part_bytes = (size_t)nq * p.S * k * 8;
+        const int P2 = (p.S + 31) / 32;
+        HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
+        HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
+        void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
+        int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
+        HVS_HIP(hipMemsetAsync(overflow, 0, 64, idx->stream));
+        p.cand = (uint64_t *)cand;
+        p.partial = (uint64_t *)bufA;
+        p.overflow = overflow;
+        HVS_TRY(hvs_prof_begin(idx));
+        if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, p.split_steps != 0, pf, grid, idx->stream, p));
+        else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, p));
+        HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
+        HVS_TRY(hvs_prof_begin(idx));
+        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, p.S, k, d_dist, d_ids, d_count));
+        HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+        int h_overflow = 0;
+        HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+        HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
+        return 0;
+    }
     // tile shape: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
     bool big = kdt != HVS_F32 && nA > Tile128::BM;
     if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;

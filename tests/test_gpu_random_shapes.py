@@ -36,8 +36,11 @@ def _cases():
     return out
 
 
+@pytest.mark.parametrize("stream", ["auto", "ring"])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
-def test_random_shapes_all_routes(hvs, dtype):
+def test_random_shapes_all_routes(hvs, dtype, stream, monkeypatch):
+    if stream == "ring":  # up to 128 embeddings: the single-query-tile ring kernel, whatever the row count
+        monkeypatch.setenv("HVS_STREAM", "1")
     rng = np.random.default_rng(7)
     for dim, n, nq, fold, k in _cases():
         rows = rng.standard_normal((n, dim)).astype(np.float32)
