@@ -75,7 +75,9 @@ def test_10m_x_1536_f32_top10(hvs):
     parts = [idx.search(torch.from_numpy(q[:16]).cuda(), k=k, row_begin=cuts[s], row_end=cuts[s + 1], algo="mfma") for s in range(3)]
     md, mi, mc = hvs.merge_topk(torch.stack([p[0] for p in parts], 1), torch.stack([p[1] for p in parts], 1),
                                 torch.stack([p[2] for p in parts], 1), k)
-    _same_up_to_ties(md.cpu().numpy(), mi.cpu().numpy(), dist[:16], ids[:16], tol=0.0)  # same kernel, same bits
+    whole = idx.search(torch.from_numpy(q[:16]).cuda(), k=k, algo="mfma")  # 16 embeddings: the same kernel as the parts
+    _same_up_to_ties(md.cpu().numpy(), mi.cpu().numpy(), whole[0].cpu().numpy(), whole[1].cpu().numpy(), tol=0.0)  # same bits
+    _same_up_to_ties(md.cpu().numpy(), mi.cpu().numpy(), dist[:16], ids[:16])  # and the 128-embedding batch's rows
     # k-means, K = 4096 (centroids = first rows): counts add up, sampled rows sit at their float64 argmin
     cent = torch.from_numpy(idx.gather(np.arange(4096))).cuda()
     assign, sums, counts = idx.kmeans_assign(cent)
