@@ -496,15 +496,19 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
 // slab of the corpus meets hi and lo of the queries in one step, the lo slab meets hi in another, so every corpus
 // byte is fetched once (the three-product order of the large-batch kernel would fetch the hi slab twice, and here
 // the corpus stream is the bound).
-template <int BM_, bool DUAL_> struct StreamTile {
-    static constexpr int BM = BM_, BN = 256, WM = 1, WN = 4;
+template <int BM_, bool DUAL_, int WM_, int WN_> struct StreamTile {
+    static constexpr int BM = BM_, BN = 256, WM = WM_, WN = WN_;
     static constexpr bool DUAL = DUAL_;
-    static constexpr int NW = 4, GT = 256;
-    static constexpr int MT = BM / 32, NT = 2;
+    static constexpr int NW = WM * WN, GT = 64 * NW;
+    static constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
     static constexpr int A_IMAGES = DUAL ? 2 : 1;
     static constexpr int STAGE_BYTES = (A_IMAGES * BM + BN) * KB;
-    static constexpr int NA = BM * KB / 16 / GT, NB = BN * KB / 16 / GT;  // LDS-DMA instructions per thread, image and k-step
-    static_assert(BM * KB / 16 % GT == 0, "whole pieces per thread");
+    // LDS-DMA instructions per thread, image and k-step.  A query image smaller than one instruction per thread is
+    // fetched by every group of A_THREADS threads alike (the same bytes to the same place): every wave then issues
+    // the same number of instructions, which the vmcnt arithmetic needs.
+    static constexpr int A_THREADS = BM * KB / 16 < GT ? BM * KB / 16 : GT;
+    static constexpr int NA = BM * KB / 16 / A_THREADS, NB = BN * KB / 16 / GT;
+    static_assert(BM * KB / 16 % A_THREADS == 0 && BN * KB / 16 % GT == 0, "whole pieces per thread");
 };
 
 // ring depth: as many stages as the 160 KB of LDS hold next to the per-query state, at most 4
@@ -525,7 +529,7 @@ __device__ __forceinline__ void stream_src_init(TileSrcT<N> &t, const void *base
 }
 
 template <int DT, int FOLD, class T>
-__global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
+__global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT, NS = stream_stages<T>();
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave;
+    const int wm = wave / T::WN, wn = wave % T::WN;
     const int s = blockIdx.x;  // one query tile: the grid is the corpus splits
     const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
     BlockState b;
@@ -552,7 +556,8 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
     const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
     TileSrcT<T::NA> srcA;
     TileSrcT<T::NB> srcB;
-    stream_src_init<T::NA>(srcA, p.A, 0, p.nA < BM ? p.nA : BM, p.lda_bytes, tid, T::GT);
+    const int tid_a = tid % T::A_THREADS, wave_a = __builtin_amdgcn_readfirstlane(tid_a >> 6);
+    stream_src_init<T::NA>(srcA, p.A, 0, p.nA < BM ? p.nA : BM, p.lda_bytes, tid_a, T::A_THREADS);
     auto init_b = [&](int64_t tile) {
         const int64_t r0 = p.row_begin + tile * BN;
         const int64_t valid = p.row_end - r0;
@@ -563,6 +568,11 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
     // arithmetic below relies on.
     auto fetch = [&](char *stage, int ks) {
         int off_a = ks * KB, off_a2 = ks * KB, off_b = ks * KB;
+        if (!T::DUAL && p.split_steps) {  // split operands, one query image: hi.hi, hi.lo, lo.hi as in mfma_search_kernel
+            const int slab = ks >= 2 * p.split_steps ? 2 : (ks >= p.split_steps ? 1 : 0), w = ks - slab * p.split_steps;
+            off_a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
+            off_b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
+        }
         if (T::DUAL) {
             const int second = ks >= p.split_steps ? 1 : 0, w = ks - second * p.split_steps;
             off_a = w * KB;
@@ -571,11 +581,12 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
         }
 #pragma unroll
         for (int i = 0; i < T::NA; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + (T::GT * i + wave * 64) * 16), 16, srcA.voff[i], off_a, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + (T::A_THREADS * i + wave_a * 64) * 16), 16, srcA.voff[i], off_a, 0,
+                                                     0);
         if (T::DUAL) {
 #pragma unroll
             for (int i = 0; i < T::NA; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + BM * KB + (T::GT * i + wave * 64) * 16), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + BM * KB + (T::A_THREADS * i + wave_a * 64) * 16), 16,
                                                          srcA.voff[i], off_a2, 0, 0);
         }
 #pragma unroll
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
         fetch_next(fslot);
         if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
         {
-            const char *As = smem + slot * STAGE_BYTES + r * KB;
+            const char *As = smem + slot * STAGE_BYTES + (wm * (MT * 32) + r) * KB;
             const char *Bs = smem + slot * STAGE_BYTES + X_IMAGE + (wn * (NT * 32) + r) * KB;
             auto frag = [&](const char *base, int t, int kc) {
                 return *reinterpret_cast<const f32x4 *>(base + t * (32 * KB) + ((kc ^ swz) << 4));
@@ -661,7 +672,7 @@ __global__ __launch_bounds__(T::GT, 1) void mfma_stream_kernel(SearchParams p) {
         }
         const bool tile_end = ks == p.nks - 1;
         if (tile_end) {
-            tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, 0, wn, lane);
+            tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
             zero_acc(acc);
         }
         // The next step's fetch (issued NS - 2 steps ago) has landed for this wave, then -- barrier -- for all of them.
@@ -714,14 +725,16 @@ static int launch_stream(int pf, int grid, hipStream_t st, const SearchParams &p
     return 0;
 }
 
+// 8 waves per block in every shape (two per SIMD): 32 rows -> 1 x 8 waves of 32 x 32, 64 -> 2 x 4 of 32 x 64, 128 -> 2 x 4 of 64 x 64
 template <int DT>
 static int launch_stream_bm(int bm, bool dual, int pf, int grid, hipStream_t st, const SearchParams &p) {
     if (dual) {
-        if (bm == 32) return launch_stream<DT, StreamTile<32, true>>(pf, grid, st, p);
-        return launch_stream<DT, StreamTile<64, true>>(pf, grid, st, p);
+        if (bm == 32) return launch_stream<DT, StreamTile<32, true, 1, 8>>(pf, grid, st, p);
+        return launch_stream<DT, StreamTile<64, true, 2, 4>>(pf, grid, st, p);
     }
-    if (bm == 32) return launch_stream<DT, StreamTile<32, false>>(pf, grid, st, p);
-    return launch_stream<DT, StreamTile<64, false>>(pf, grid, st, p);
+    if (bm == 32) return launch_stream<DT, StreamTile<32, false, 1, 8>>(pf, grid, st, p);
+    if (bm == 64) return launch_stream<DT, StreamTile<64, false, 2, 4>>(pf, grid, st, p);
+    return launch_stream<DT, StreamTile<128, false, 2, 4>>(pf, grid, st, p);
 }
 
 #define HVS_COMPACT_MAX_BYTES ((size_t)16 << 30)  // largest dense copy a filtered search may make
@@ -877,11 +890,15 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.k = k;
     p.thr = thr;
     // one query tile of 16-bit operands and enough rows to keep every CU streaming: the ring kernel
-    bool stream = kdt != HVS_F32 && nA <= 64 && row_end - row_begin >= 256 * 256;
-    if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= 64 && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
+    const int stream_max = 128;
+    bool stream = kdt != HVS_F32 && nA <= stream_max && row_end - row_begin >= 256 * 256;
+    if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= stream_max && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
     if (stream) {
-        const int bm = nA <= 32 ? 32 : 64;
-        if (p.split_steps) p.nks = 2 * p.split_steps;  // (A hi, A lo | X hi) steps, then (A hi | X lo) steps
+        const int bm = nA <= 32 ? 32 : (nA <= 64 ? 64 : 128);
+        // split copy: up to 64 rows both query slabs ride in a stage -- (A hi, A lo | X hi) steps, then (A hi | X lo) steps;
+        // two query images of 128 rows would leave no room for a third stage, so that tile keeps the three-product order
+        const bool dual = p.split_steps != 0 && bm <= 64;
+        if (dual) p.nks = 2 * p.split_steps;
         p.cap = CAND_MAX;
         p.QT = 1;
         p.T = (row_end - row_begin + 255) / 256;
@@ -901,7 +918,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         p.partial = (uint64_t *)bufA;
         p.overflow = overflow;
         HVS_TRY(hvs_prof_begin(idx));
-        if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, p.split_steps != 0, pf, grid, idx->stream, p));
+        if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, dual, pf, grid, idx->stream, p));
         else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, p));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
         HVS_TRY(hvs_prof_begin(idx));
