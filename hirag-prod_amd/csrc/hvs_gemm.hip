@@ -833,7 +833,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // fp32 rows on the 16-bit pipe: decided first, because a filtered search gathers from whichever copy is contracted
     bool use_split = false;
     if (idx->dtype == HVS_F32 && split_mode != 0 && !getenv("HVS_NO_SPLIT") &&
-        (split_mode == 1 || nA >= 64 || (idx->split && idx->split_n == idx->n)))
+        (split_mode == 1 || nA >= 16 || (idx->split && idx->split_n == idx->n)))
         HVS_TRY(hvs_split_ensure(idx, &use_split));
     const void *src_rows = use_split ? idx->split : idx->rows;
     const float *src_inv = use_split ? idx->split_inv : idx->inv_norm;

@@ -854,7 +854,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         use_mfma = false;
     }
     if (use_mfma)
-        // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy for batches that repay building it
+        // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy if it exists or from 16 embeddings on
         HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
                                 algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_MFMA ? 1 : 2)));
     else

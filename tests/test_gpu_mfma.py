@@ -93,7 +93,7 @@ def test_split_copy_keeps_fp32_grade_scores(hvs):
         np.testing.assert_array_equal(c3, cnt)
         np.testing.assert_allclose(d3, dist, atol=2e-6)
     assert ids[2, 0] == 700 and dist[2, 0] < 2e-6 and ids[3, 0] == 1200 and dist[3, 0] < 2e-6
-    # fold over the split path, and the auto dispatch (>= 64 embeddings take it for fp32 rows)
+    # fold over the split path, and the auto dispatch (from 16 embeddings on fp32 rows take it)
     dist, ids, cnt = idx.search(q, k=10, fold=3, algo="mfma")
     _check_all(rows, q, 3, 10, dist, ids, cnt, label="split fold 3")
     dist, ids, cnt = idx.search(q, k=10)
