@@ -277,6 +277,25 @@ def main():
                 "extra_device_memory_bytes": int((hi - lo) * ((DIM + 63) // 64 * 64) * 4),
             }
 
+        # mid-size batch on the same corpus: 64 queries per call (the library's default route: ring kernel on the split copy)
+        q64 = queries[:64].contiguous()
+        for _ in range(2):
+            searcher.search(q64, TOPK)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        reps64 = 10
+        for _ in range(reps64):
+            searcher.search(q64, TOPK)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e3 = time.perf_counter() - t0
+        if rank == 0:
+            result["aux"]["batch_of_64"] = {"qps": 64 * reps64 / e3, "ms_per_batch": e3 / reps64 * 1e3,
+                                            "hbm_floor_ms": (hi - lo) * DIM * 4 / (HBM_PEAK_GBS * 1e9) * 1e3}
+
     if rank == 0:
         # timed at N = 1 only, on this host's cores (at most 16: the GPU box's CPU share per GPU)
         if world == 1 and not args.no_cpu_baseline:
