@@ -250,6 +250,38 @@ class HipVectorStore(BaseVDB):
             logger.info(f"[upsert_texts] No rows to upsert into '{table_name}', mode={mode}, elapsed={time.perf_counter() - start:.3f}s")
             return rows
 
+        await self._insert_rows(table, table_name, rows)
+        logger.info("[upsert_texts] Upserted %d into '%s', mode=%s, elapsed=%.3fs", len(rows), table_name, mode,
+                    time.perf_counter() - start)
+        return rows
+
+    async def load_rows(self, table_name: str, rows, vector_key: str = "vector_float_array") -> int:
+        """Bulk ingest of rows that already carry their embedding: the sync-from-PostgreSQL path.  ``rows``
+        is an iterable of mappings as ``dict(orm_row)`` of the reference's models gives them; the vector is
+        taken from ``vector_float_array`` (the ``cast(vector, ARRAY(Float(4)))`` column property,
+        ``src/hirag_prod/schema/chunk.py:46-48``, ``item.py:59``, ``triplets.py:26``), else from ``vector``
+        (a list, a numpy array or a pgvector ``HalfVector`` / ``Vector`` with ``to_list()``).  Same rules
+        as ``upsert_texts`` otherwise (first write wins on the primary key, type rounding, range checks);
+        no embedding call.  Returns the number of rows offered."""
+        table = self.get_model(table_name)
+        if not table.has_vector:
+            raise ValueError(f"table {table_name} has no vector column")
+        prepared: List[dict] = []
+        for src in rows:
+            row = dict(src)
+            vec = row.pop(vector_key, None)
+            if vec is None:
+                vec = row.get("vector")
+            if vec is None:
+                raise ValueError(f"row without a vector ({vector_key!r} or 'vector') for table {table_name}")
+            row["vector"] = vec.to_list() if hasattr(vec, "to_list") else self._to_list(vec)
+            prepared.append({k: v for k, v in row.items() if k in table.colset})
+        if prepared:
+            await self._insert_rows(table, table_name, prepared)
+        return len(prepared)
+
+    async def _insert_rows(self, table: _Table, table_name: str, rows: List[dict]) -> None:
+        """Append the rows whose primary key is new (``ON CONFLICT DO NOTHING``) to the host table and the index."""
         async with self._lock:
             new_vecs, new_rows = [], []
             seen_in_batch = set()
@@ -295,9 +327,6 @@ class HipVectorStore(BaseVDB):
                 mat = np.stack(new_vecs)
                 lo, hi = await asyncio.to_thread(index.add, mat, None, groups)
                 assert lo == first and hi == first + n_new, "host rows and device rows out of step"
-        logger.info("[upsert_texts] Upserted %d into '%s', mode=%s, elapsed=%.3fs", len(rows), table_name, mode,
-                    time.perf_counter() - start)
-        return rows
 
     async def upsert_file(self, file, table_name: str = "Files", mode: str = "append"):
         """Insert one Files row unless its primary key exists (pgvector.py:475-503)."""

@@ -305,6 +305,55 @@ async def scenario_graph_and_fusion(store, storage):
     assert await store.clean_table("Nodes", {"node_id": "ent-3"}) is False
 
 
+async def scenario_load_rows(store, other, storage):
+    """Rows that already carry vectors (what a sync from the reference's PostgreSQL tables yields) give the
+    same store as embedding the same texts."""
+    await store._init_vdb(embedding_dimension=DIM)
+    await other._init_vdb(embedding_dimension=DIM)
+    props = [chunk_props(i, ws="ws1" if i % 2 else "ws2") for i in range(90)]
+    texts = [p["text"] for p in props]
+    await other.upsert_texts(texts, props, "Chunks")
+
+    class HalfVectorLike:  # shape of pgvector's value objects
+        def __init__(self, v):
+            self._v = v
+
+        def to_list(self):
+            return list(self._v)
+
+    rows = []
+    for i, p in enumerate(props):
+        row = {k: v for k, v in p.items()}
+        vec = embed_text(texts[i]).astype(np.float32)
+        if i % 3 == 0:
+            row["vector_float_array"] = vec.tolist()
+        elif i % 3 == 1:
+            row["vector"] = HalfVectorLike(vec)
+        else:
+            row["vector"] = vec
+        rows.append(row)
+    assert await store.load_rows("Chunks", rows) == len(rows)
+    assert await store.load_rows("Chunks", rows[:10]) == 10  # same keys again: nothing new
+    for q in ("text ws1 kb1 11", "text ws2 kb1 4"):
+        for ws in ("ws1", "ws2"):
+            a = await store.query(q, ws, "kb1", "Chunks", topk=15, distance_threshold=1.5)
+            b = await other.query(q, ws, "kb1", "Chunks", topk=15, distance_threshold=1.5)
+            assert [r["documentKey"] for r in a] == [r["documentKey"] for r in b]
+            np.testing.assert_allclose([r["distance"] for r in a], [r["distance"] for r in b], atol=1e-6)
+    got = await store.query_by_keys([props[5]["documentKey"]], "ws1", "kb1", "Chunks", columns_to_select=["documentKey", "vector"])
+    np.testing.assert_array_equal(np.array(got[0]["vector"].to_list(), dtype=np.float32),
+                                  po.round_storage(embed_text(texts[5]), storage).astype(np.float32))
+    assert "vector_float_array" not in (await store.get_table("Chunks"))[0]
+    for bad in ([{**props[0], "documentKey": "x"}], [{**props[0], "documentKey": "y", "vector": [1.0] * (DIM + 1)}],
+                [{**props[0], "documentKey": "z", "vector": [float("nan")] * DIM}]):
+        try:
+            await store.load_rows("Chunks", bad)
+        except ValueError:
+            pass
+        else:
+            raise AssertionError("expected ValueError")
+
+
 async def scenario_many_embeddings(store, storage):
     """More query variants than one launch folds (9 > 8): still the exact LEAST."""
     await store._init_vdb(embedding_dimension=DIM)

@@ -29,6 +29,14 @@ def test_store_graph_and_fusion_gpu():
     s.close()
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
+def test_store_load_rows_gpu(vector_type, storage):
+    a, b = _store(vector_type), _store(vector_type)
+    store_cases.run(store_cases.scenario_load_rows(a, b, storage))
+    a.close()
+    b.close()
+
+
 def test_store_many_embeddings_gpu():
     s = _store("halfvec")
     store_cases.run(store_cases.scenario_many_embeddings(s, "f16"))
