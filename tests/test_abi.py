@@ -47,3 +47,15 @@ def test_errors_cross_the_boundary_as_messages():
     assert lib.hvs_index_destroy(None) == 0
     with pytest.raises(hvs.HvsError):
         hvs.HvsIndex(8, "f32", device=10_000)
+
+
+def test_header_is_plain_c_and_cxx():
+    """The boundary is a C ABI: the header must compile as C99 and as C++ without any other include."""
+    import shutil
+    import subprocess
+
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "hvs.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", header])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", header])
