@@ -46,6 +46,7 @@ struct SearchParams {
     int *overflow;  // set to 1 if a candidate array ever overflowed (must stay 0)
     unsigned long long *prof;  // timing experiments only: per-phase cycle sums of wave 0 lanes (HVS_DBG & 512)
     const uint32_t *remap;  // optional: X holds a compacted copy; remap[r] = row position of its row r in the index
+    float *dist_out;  // distance-column kernels: LEAST over all A rows of every corpus row, [row_end - row_begin]
     int split_steps;  // 0: plain operands.  > 0: both operands hold rows [hi slab | lo slab] of split_steps k-steps each
                       // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
@@ -513,7 +514,7 @@ template <int BM_, bool DUAL_, int WM_, int WN_> struct StreamTile {
 
 // ring depth: as many stages as the 160 KB of LDS hold next to the per-query state, at most 4
 template <class T> __host__ __device__ constexpr int stream_stages() {
-    return T::STAGE_BYTES * 4 + T::BM * 16 <= 160 * 1024 - 1024 ? 4 : 3;
+    return T::STAGE_BYTES * 4 + T::BM * 16 + 1024 <= 160 * 1024 - 1024 ? 4 : 3;
 }
 
 template <int N>
@@ -528,7 +529,9 @@ __device__ __forceinline__ void stream_src_init(TileSrcT<N> &t, const void *base
     for (int i = 0; i < N; i++) t.voff[i] = dma_src_offset(tid, i, pitch_bytes, rows_valid - 1, threads);
 }
 
-template <int DT, int FOLD, class T>
+// DISTCOL: no selection at all -- every corpus row's LEAST over the A rows goes to p.dist_out (the projected
+// distance column of cross-language search with many sentence embeddings in one pass over the rows).
+template <int DT, int FOLD, class T, bool DISTCOL = false>
 __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -547,11 +550,14 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
     b.cnt = reinterpret_cast<int *>(b.tau + BM);
     b.qinv = reinterpret_cast<float *>(b.cnt + BM);
     b.bound = b.qinv + BM;
-    b.my_cand = p.cand + (size_t)blockIdx.x * (BM / FOLD) * p.cap;
+    b.my_cand = DISTCOL ? nullptr : p.cand + (size_t)blockIdx.x * (BM / FOLD) * p.cap;
     block_state_init<T>(p, b, 0, tid);
+    float *xch = b.bound + BM;  // DISTCOL with two wave rows: [WN][NT][32] minima handed from wave row 1 to wave row 0
 
     f32x16 acc[MT][NT];
     float invn2[NT];
+    float colmin[NT];  // DISTCOL: this lane's rows' minima over the wave's A rows, kept across the step barrier
+    int64_t col_tile = 0;
     zero_acc(acc);
     const int64_t total_steps = (tile_hi - tile_lo) * p.nks;
     TileSrcT<T::NA> srcA;
@@ -672,7 +678,30 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
         }
         const bool tile_end = ks == p.nks - 1;
         if (tile_end) {
-            tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+            if (DISTCOL) {
+                // rows on lanes, A rows on accumulator registers: fminf drops the NaN of a zero-norm embedding, a
+                // zero-norm row stays NaN; A rows past nA are padding and take no part
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    float m = __builtin_nanf("");
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) {
+                            const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;
+                            const f32x4 qi = *reinterpret_cast<const f32x4 *>(b.qinv + a_loc);
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (a_loc + e < p.nA) m = fminf(m, hvs_cos_dist(acc[mt][nt][4 * gq + e], invn2[nt], qi[e]));
+                        }
+                    m = fminf(m, __shfl_xor(m, 32));  // the other lane half holds the other A rows of the same corpus row
+                    colmin[nt] = m;
+                    if (T::WM == 2 && wm == 1 && h == 0) xch[(wn * NT + nt) * 32 + r] = m;
+                }
+                col_tile = tile;
+            } else {
+                tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+            }
             zero_acc(acc);
         }
         // The next step's fetch (issued NS - 2 steps ago) has landed for this wave, then -- barrier -- for all of them.
@@ -680,7 +709,25 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
         // covers what was issued before them.  The candidate keys a tile's epilogue stores are ranked one step
         // later (compact_due): by then only the fetch issued after them may still be in flight, and the ring never
         // drains.  A K loop of a single step has no later step before the next epilogue and drains instead.
-        if (p.nks == 1) {
+        if (DISTCOL) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES * (NS - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tile_end && wm == 0 && h == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    float m = colmin[nt];
+                    if (T::WM == 2) m = fminf(m, xch[(wn * NT + nt) * 32 + r]);
+                    const int64_t row = p.row_begin + col_tile * BN + wn * (NT * 32) + nt * 32 + r;
+                    if (row < p.row_end) p.dist_out[row - p.row_begin] = m;
+                }
+            }
+            if (tile_end && p.nks == 1) {  // the exchange area is rewritten a whole K loop later otherwise
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        } else if (p.nks == 1) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -702,11 +749,12 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block
     __syncthreads();
-    publish_lists<FOLD, T>(p, b, 0, s, wave, lane);
+    if (!DISTCOL) publish_lists<FOLD, T>(p, b, 0, s, wave, lane);
 #endif
 }
 
-template <class T> static size_t stream_lds_bytes() { return (size_t)stream_stages<T>() * T::STAGE_BYTES + T::BM * 16; }
+// stages + per-query state + (distance-column kernels) the 1 KB exchange area
+template <class T> static size_t stream_lds_bytes() { return (size_t)stream_stages<T>() * T::STAGE_BYTES + T::BM * 16 + 1024; }
 
 template <int DT, class T>
 static int launch_stream(int pf, int grid, hipStream_t st, const SearchParams &p) {
@@ -735,6 +783,27 @@ static int launch_stream_bm(int bm, bool dual, int pf, int grid, hipStream_t st,
     if (bm == 32) return launch_stream<DT, StreamTile<32, false, 1, 8>>(pf, grid, st, p);
     if (bm == 64) return launch_stream<DT, StreamTile<64, false, 2, 4>>(pf, grid, st, p);
     return launch_stream<DT, StreamTile<128, false, 2, 4>>(pf, grid, st, p);
+}
+
+template <int DT, class T>
+static int launch_distcol(int grid, hipStream_t st, const SearchParams &p) {
+    const size_t lds = stream_lds_bytes<T>();
+    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_stream_kernel<DT, 1, T, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    mfma_stream_kernel<DT, 1, T, true><<<grid, T::GT, lds, st>>>(p);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int DT>
+static int launch_distcol_bm(int bm, bool dual, int grid, hipStream_t st, const SearchParams &p) {
+    if (dual) {
+        if (bm == 32) return launch_distcol<DT, StreamTile<32, true, 1, 8>>(grid, st, p);
+        return launch_distcol<DT, StreamTile<64, true, 2, 4>>(grid, st, p);
+    }
+    if (bm == 32) return launch_distcol<DT, StreamTile<32, false, 1, 8>>(grid, st, p);
+    if (bm == 64) return launch_distcol<DT, StreamTile<64, false, 2, 4>>(grid, st, p);
+    return launch_distcol<DT, StreamTile<128, false, 2, 4>>(grid, st, p);
 }
 
 #define HVS_COMPACT_MAX_BYTES ((size_t)16 << 30)  // largest dense copy a filtered search may make
@@ -789,6 +858,75 @@ static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p
     else HVS_LAUNCH_SEARCH(4);
 #undef HVS_LAUNCH_SEARCH
     HVS_HIP(hipGetLastError());
+    return 0;
+}
+
+// LEAST over m <= 128 prepared embeddings of the distance to every row of [row_begin, row_end), in one pass over the
+// rows on the matrix pipe.  *used = false when this route does not apply (fp32 rows whose split copy is neither
+// current nor worth building); the caller then streams the rows once per 8 embeddings.
+int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int m, int64_t row_begin, int64_t row_end, float *d_out,
+                       bool *used) {
+    *used = false;
+    if (m < 1 || m > 128 || row_end <= row_begin || getenv("HVS_NO_MFMA_DIST")) return 0;
+    bool use_split = false;
+    if (idx->dtype == HVS_F32) {
+        if (getenv("HVS_NO_SPLIT") || !(m >= 16 || (idx->split && idx->split_n == idx->n))) return 0;
+        HVS_TRY(hvs_split_ensure(idx, &use_split));
+        if (!use_split) return 0;
+    }
+    const int esz = idx->elem_size;
+    const int ld_bytes = idx->ld * esz;
+    const int lda_bytes = (ld_bytes + KB - 1) / KB * KB;
+    const int lda = lda_bytes / esz;
+    const int ld16 = (idx->dim + 63) / 64 * 64;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t a_bytes = up((size_t)m * lda_bytes), a_inv_bytes = up((size_t)m * 4);
+    void *a_ws = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + (use_split ? up((size_t)m * ld16 * 4) + up((size_t)m * 4) : 0), &a_ws));
+    float *A_inv = (float *)((char *)a_ws + a_bytes);
+    if (idx->dtype == HVS_F32) build_a_kernel<float><<<m, 256, 0, idx->stream>>>(d_q, d_qinv, (float *)a_ws, A_inv, 1, 1, idx->ld, lda);
+    else if (idx->dtype == HVS_F16) build_a_kernel<__half><<<m, 256, 0, idx->stream>>>(d_q, d_qinv, (__half *)a_ws, A_inv, 1, 1, idx->ld, lda);
+    else build_a_kernel<uint16_t><<<m, 256, 0, idx->stream>>>(d_q, d_qinv, (uint16_t *)a_ws, A_inv, 1, 1, idx->ld, lda);
+    HVS_HIP(hipGetLastError());
+
+    SearchParams p;
+    memset(&p, 0, sizeof(p));
+    p.A = a_ws;
+    p.q_inv = A_inv;
+    p.nA = m;
+    p.lda_bytes = lda_bytes;
+    p.X = idx->rows;
+    p.inv_norm = idx->inv_norm;
+    p.ld_bytes = ld_bytes;
+    p.nks = lda_bytes / KB;
+    p.group_filter = -1;
+    p.row_begin = row_begin;
+    p.row_end = row_end;
+    p.thr = INFINITY;
+    p.dist_out = d_out;
+    const int bm = m <= 32 ? 32 : (m <= 64 ? 64 : 128);
+    bool dual = false;
+    if (use_split) {
+        char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
+        float *a_split_inv = (float *)(a_split + up((size_t)m * ld16 * 4));
+        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, m, lda, lda, ld16, a_split, a_split_inv));
+        p.A = a_split;
+        p.q_inv = a_split_inv;
+        p.lda_bytes = p.ld_bytes = ld16 * 4;
+        p.X = idx->split;
+        p.inv_norm = idx->split_inv;
+        p.split_steps = ld16 * 2 / KB;
+        dual = bm <= 64;
+        p.nks = (dual ? 2 : 3) * p.split_steps;
+    }
+    p.QT = 1;
+    p.T = (row_end - row_begin + 255) / 256;
+    p.S = (int)(p.T < 256 ? p.T : 256);
+    HVS_TRY(hvs_prof_begin(idx));
+    if (idx->dtype == HVS_BF16) HVS_TRY(launch_distcol_bm<HVS_BF16>(bm, false, p.S, idx->stream, p));
+    else HVS_TRY(launch_distcol_bm<HVS_F16>(bm, dual, p.S, idx->stream, p));
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
+    *used = true;
     return 0;
 }
 

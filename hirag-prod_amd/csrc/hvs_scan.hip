@@ -869,11 +869,47 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     return 0;
 }
 
-// distance column of rows [row_begin, row_end) into the device buffer d_out (queries as hvs_distances takes them)
+int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int m, int64_t row_begin, int64_t row_end, float *d_out,
+                       bool *used);  // hvs_gemm.hip
+
+__global__ void fmin_columns_kernel(float *__restrict__ acc, const float *__restrict__ other, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc[i] = fminf(acc[i], other[i]);  // NaN only where both are NaN
+}
+
+static int distance_column_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int fold, int64_t row_begin, int64_t row_end,
+                                float *d_out, const char *who);
+
+// distance column of rows [row_begin, row_end) into the device buffer d_out (queries as hvs_distances takes them):
+// from five embeddings on in one pass on the matrix pipe where that route applies, else one streaming pass per 8
 static int distance_column(hvs_index *idx, const float *queries, int fold, int on_device, int64_t row_begin, int64_t row_end,
                            float *d_out, const char *who) {
     float *d_q = nullptr, *d_qinv = nullptr;
     HVS_TRY(hvs_prepare_queries(idx, queries, fold, on_device, &d_q, &d_qinv));
+    if (fold >= 5) {
+        bool used = false;
+        HVS_TRY(hvs_distances_mfma(idx, d_q, d_qinv, fold, row_begin, row_end, d_out, &used));
+        if (used) return 0;
+    }
+    if (fold <= HVS_MAX_FOLD) return distance_column_scan(idx, d_q, d_qinv, fold, row_begin, row_end, d_out, who);
+    const int64_t n_rows = row_end - row_begin;
+    void *tmp = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 6, (size_t)n_rows * 4 + 256, &tmp));
+    for (int first = 0; first < fold; first += HVS_MAX_FOLD) {
+        const int part = fold - first < HVS_MAX_FOLD ? fold - first : HVS_MAX_FOLD;
+        HVS_TRY(distance_column_scan(idx, d_q + (size_t)first * idx->ld, d_qinv + first, part, row_begin, row_end,
+                                     first == 0 ? d_out : (float *)tmp, who));
+        if (first) {
+            int g = (int)((n_rows + 255) / 256);
+            fmin_columns_kernel<<<g > 2048 ? 2048 : g, 256, 0, idx->stream>>>(d_out, (const float *)tmp, n_rows);
+            HVS_HIP(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
+static int distance_column_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int fold, int64_t row_begin, int64_t row_end,
+                                float *d_out, const char *who) {
     const int64_t n_rows = row_end - row_begin;
     const int NQ = round_nq(fold);
     const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, 1, 1, scan_rows_in_flight(NQ, idx->elem_size));
@@ -907,7 +943,7 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
                              float *out, int on_device) {
     HVS_REQUIRE(idx != nullptr, "hvs_distances: idx is NULL");
     HVS_REQUIRE(queries && out, "hvs_distances: NULL argument");
-    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_distances: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_DIST_FOLD, "hvs_distances: fold %d not in [1, %d]", fold, HVS_MAX_DIST_FOLD);
     if (row_end < 0 || row_end > idx->n) row_end = idx->n;
     if (row_begin < 0) row_begin = 0;
     if (row_begin >= row_end) return 0;
@@ -933,7 +969,7 @@ extern "C" int hvs_range_search(hvs_index *idx, const float *queries, int fold, 
     HVS_REQUIRE(idx != nullptr, "hvs_range_search: idx is NULL");
     HVS_REQUIRE(queries && out_total, "hvs_range_search: NULL argument");
     HVS_REQUIRE(capacity >= 0 && (capacity == 0 || (out_dist && out_ids)), "hvs_range_search: outputs missing for capacity %lld", (long long)capacity);
-    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_range_search: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_DIST_FOLD, "hvs_range_search: fold %d not in [1, %d]", fold, HVS_MAX_DIST_FOLD);
     if (row_end < 0 || row_end > idx->n) row_end = idx->n;
     if (row_begin < 0) row_begin = 0;
     int64_t total = 0;

@@ -38,6 +38,7 @@ logger = logging.getLogger(__name__)
 
 _HALF_MAX = 65504.0
 _MAX_FOLD = 8  # HVS_MAX_FOLD
+_MAX_DIST_FOLD = 128  # HVS_MAX_DIST_FOLD: embeddings per call of the distance column / range search
 
 
 class StoredVector(list):
@@ -615,8 +616,8 @@ class HipVectorStore(BaseVDB):
             if empty:
                 return []
             best: Dict[int, float] = {}
-            for s in range(0, q.shape[0], _MAX_FOLD):  # LEAST < bound iff some group's LEAST < bound
-                dist, ids, _ = await asyncio.to_thread(table.index.range_search, q[s : s + _MAX_FOLD], float(max_distance),
+            for s in range(0, q.shape[0], _MAX_DIST_FOLD):  # LEAST < bound iff some group's LEAST < bound
+                dist, ids, _ = await asyncio.to_thread(table.index.range_search, q[s : s + _MAX_DIST_FOLD], float(max_distance),
                                                        group_filter, mask)
                 for pos, d in zip(ids.tolist(), dist.tolist()):
                     if pos not in best or d < best[pos]:
@@ -629,8 +630,8 @@ class HipVectorStore(BaseVDB):
                 out.append(rec)
             return out
         col = None
-        for s in range(0, q.shape[0], _MAX_FOLD):
-            part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_FOLD])
+        for s in range(0, q.shape[0], _MAX_DIST_FOLD):
+            part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_DIST_FOLD])
             col = part if col is None else np.fmin(col, part)  # fmin: NaN only if both are NaN
         out = []
         for pos, row in enumerate(table.rows):

@@ -51,6 +51,7 @@ enum { HVS_PROF_SCAN = 0, HVS_PROF_MFMA_SEARCH = 1, HVS_PROF_KMEANS_ASSIGN = 2, 
 
 #define HVS_MAX_K 1024       /* largest top-k a search accepts */
 #define HVS_MAX_FOLD 8       /* largest number of query embeddings folded by LEAST */
+#define HVS_MAX_DIST_FOLD 128 /* ... by hvs_distances / hvs_range_search (no ranking: one pass on the matrix pipe, or one per 8) */
 
 const char *hvs_last_error(void);
 int hvs_version(void);

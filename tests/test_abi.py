@@ -33,6 +33,7 @@ def test_constants_match_header():
     text = open(os.path.join(ROOT, "include", "hvs.h")).read()
     assert int(re.search(r"#define HVS_MAX_K (\d+)", text).group(1)) == _lib.HVS_MAX_K
     assert int(re.search(r"#define HVS_MAX_FOLD (\d+)", text).group(1)) == _lib.HVS_MAX_FOLD
+    assert int(re.search(r"#define HVS_MAX_DIST_FOLD (\d+)", text).group(1)) == _lib.HVS_MAX_DIST_FOLD
 
 
 def test_errors_cross_the_boundary_as_messages():

@@ -386,3 +386,50 @@ def test_range_search_matches_the_distance_column(hvs, dtype):
     empty = hvs.HvsIndex(d, dtype)
     assert empty.range_search(q[:1], 0.4)[2] == 0
     empty.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_distance_column_of_many_embeddings(hvs, dtype):
+    """The projected column of cross-language search takes one embedding per sentence of the query
+    (``LEAST`` over all of them, pgvector.py:561-585): up to 128 in one call.  From five embeddings on the
+    column comes from one pass on the matrix pipe (fp32 tables: through the split copy, built from 16 on);
+    the other route, one streaming pass per eight embeddings, must give the same column."""
+    rng = np.random.default_rng(909)
+    for n, d in ((3001, 96), (70001, 200), (5000, 1536)):
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        rows[11] = 0.0  # NaN for every embedding: stays NaN
+        rows[n - 1] *= 1e-3
+        q = rng.standard_normal((128, d)).astype(np.float32)
+        q[2] = 0.0  # a zero embedding takes no part in LEAST
+        q[40] = rows[n - 2]  # distance ~0 to one row
+        idx = _mk(hvs, rows, dtype)
+        dm = parity.distance_matrix(rows, q, dtype)
+        for m in (5, 8, 9, 16, 31, 33, 64, 65, 100, 128):
+            full = po.least_fold(dm[:m])
+            for lo, hi in ((0, -1), (257, n - 300)):
+                want = full[lo : (n if hi < 0 else hi)]
+                cols = {}
+                for route in ("matrix", "stream"):
+                    if route == "stream":
+                        os.environ["HVS_NO_MFMA_DIST"] = "1"
+                    try:
+                        cols[route] = idx.distances(q[:m], row_begin=lo, row_end=hi)
+                    finally:
+                        os.environ.pop("HVS_NO_MFMA_DIST", None)
+                    label = f"{dtype} n={n} d={d} m={m} [{lo},{hi}) {route}"
+                    assert cols[route].shape == want.shape, label
+                    assert np.array_equal(np.isnan(cols[route]), np.isnan(want)), label
+                    np.testing.assert_allclose(cols[route], want, atol=1e-5, err_msg=label)
+                np.testing.assert_allclose(cols["matrix"], cols["stream"], atol=3e-6)
+        # the selection built on the column
+        full = po.least_fold(dm[:50]).astype(np.float64)
+        dist, ids, total = idx.range_search(q[:50], 0.9)
+        with np.errstate(invalid="ignore"):
+            sure, maybe = full < 0.9 - 2e-6, full < 0.9 + 2e-6
+        got = np.zeros(n, bool)
+        got[ids] = True
+        assert total == len(ids) and not np.any(sure & ~got) and not np.any(got & ~maybe)
+        np.testing.assert_allclose(dist, full[ids], atol=1e-5)
+        with pytest.raises(hvs.HvsError):
+            idx.distances(np.ones((129, d), np.float32))
+        idx.close()
