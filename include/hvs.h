@@ -158,7 +158,9 @@ int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k,
  * column of cross-language search
  * (src/hirag_prod/cross_language_search/search_service.py:100-113):
  * out[r - row_begin] = LEAST_j(distance(row r, q_j)) for every row of the
- * range, NaN where undefined; no filtering, no ordering.
+ * range, NaN where undefined; no filtering, no ordering.  fold counts the
+ * sentence embeddings of one query, 1 .. HVS_MAX_DIST_FOLD (the same limit
+ * holds for hvs_range_search).
  */
 int hvs_distances(hvs_index *idx, const float *queries, int fold,
                   int64_t row_begin, int64_t row_end, float *out, int on_device);
