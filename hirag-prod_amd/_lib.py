@@ -15,14 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libhvs.so")
 
 HVS_F32, HVS_F16, HVS_BF16 = 0, 1, 2
-HVS_ALGO_AUTO, HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32 = 0, 1, 2, 3
+HVS_ALGO_AUTO, HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32, HVS_ALGO_MFMA_SPLIT = 0, 1, 2, 3, 4
 HVS_PROF_SCAN, HVS_PROF_MFMA_SEARCH, HVS_PROF_KMEANS_ASSIGN, HVS_PROF_KMEANS_UPDATE, HVS_PROF_MERGE = range(5)
 HVS_MAX_K = 1024
 HVS_MAX_FOLD = 8
 HVS_MAX_DIST_FOLD = 128
 
 DTYPE_CODE = {"f32": HVS_F32, "f16": HVS_F16, "bf16": HVS_BF16}
-ALGO_CODE = {"auto": HVS_ALGO_AUTO, "scan": HVS_ALGO_SCAN, "mfma": HVS_ALGO_MFMA, "mfma_f32": HVS_ALGO_MFMA_F32}
+ALGO_CODE = {"auto": HVS_ALGO_AUTO, "scan": HVS_ALGO_SCAN, "mfma": HVS_ALGO_MFMA, "mfma_f32": HVS_ALGO_MFMA_F32,
+             "mfma_split": HVS_ALGO_MFMA_SPLIT}
 
 # name -> (restype, argtypes): every symbol include/hvs.h declares
 SIGNATURES = {

@@ -19,6 +19,8 @@
 // capacity one wave ranks it, keeps the best k and lowers tau.
 #include "hvs_gemm_tile.h"
 
+#include <vector>
+
 // ---------------------------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------------------------
@@ -497,8 +499,8 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
 // slab of the corpus meets hi and lo of the queries in one step, the lo slab meets hi in another, so every corpus
 // byte is fetched once (the three-product order of the large-batch kernel would fetch the hi slab twice, and here
 // the corpus stream is the bound).
-template <int BM_, bool DUAL_, int WM_, int WN_> struct StreamTile {
-    static constexpr int BM = BM_, BN = 256, WM = WM_, WN = WN_;
+template <int BM_, bool DUAL_, int WM_, int WN_, int BN_ = 256> struct StreamTile {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
     static constexpr bool DUAL = DUAL_;
     static constexpr int NW = WM * WN, GT = 64 * NW;
     static constexpr int MT = BM / WM / 32, NT = BN / WN / 32;
@@ -553,6 +555,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
     b.my_cand = DISTCOL ? nullptr : p.cand + (size_t)blockIdx.x * (BM / FOLD) * p.cap;
     block_state_init<T>(p, b, 0, tid);
     float *xch = b.bound + BM;  // DISTCOL with two wave rows: [WN][NT][32] minima handed from wave row 1 to wave row 0
+    static_assert(!DISTCOL || (T::WM <= 2 && BN <= 256), "the exchange area holds one wave row's minima of 256 corpus rows");
 
     f32x16 acc[MT][NT];
     float invn2[NT];
@@ -811,8 +814,11 @@ static int launch_distcol_bm(int bm, bool dual, int grid, hipStream_t st, const 
 // ---------------------------------------------------------------------------------------------
 // host side of the search
 // ---------------------------------------------------------------------------------------------
+int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
+                    int32_t *d_count);  // hvs_scan.hip
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
-                     int64_t *d_ids, int32_t *d_count);
+                     int64_t *d_ids, int32_t *d_count, bool positions);
 
 template <class T> static size_t search_lds_bytes() { return (size_t)2 * T::STAGE_BYTES + T::BM * 16; }
 
@@ -933,6 +939,9 @@ int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, in
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
                     int64_t *d_ids, int32_t *d_count, int split_mode) {
+    // split_mode 3 (fp32 rows with a current split copy; hvs_search_rescore): the filter pass -- one product over the
+    // hi slabs alone (approximate scores), d_ids receives row positions
+    const bool hi_only = split_mode == 3;
     const int pf = padded_fold(fold);
     const int nA = nq * pf;
     const int esz = idx->elem_size;
@@ -971,7 +980,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // fp32 rows on the 16-bit pipe: decided first, because a filtered search gathers from whichever copy is contracted
     bool use_split = false;
     if (idx->dtype == HVS_F32 && split_mode != 0 && !getenv("HVS_NO_SPLIT") &&
-        (split_mode == 1 || nA >= 16 || (idx->split && idx->split_n == idx->n)))
+        (split_mode == 1 || split_mode == 3 || nA >= 16 || (idx->split && idx->split_n == idx->n)))
         HVS_TRY(hvs_split_ensure(idx, &use_split));
     const void *src_rows = use_split ? idx->split : idx->rows;
     const float *src_inv = use_split ? idx->split_inv : idx->inv_norm;
@@ -1020,26 +1029,30 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         p.A = a_split;
         p.q_inv = a_split_inv;
         p.lda_bytes = lda_bytes = ld16 * 4;
-        p.split_steps = ld16 * 2 / KB;
+        p.split_steps = hi_only ? 0 : ld16 * 2 / KB;  // hi slabs alone: plain operands that end half way through a row
     }
+    HVS_REQUIRE(!hi_only || use_split, "hvs_search: the filter pass needs the split copy");
     p.ld_bytes = ld_bytes;
-    p.nks = p.split_steps ? 3 * p.split_steps : lda_bytes / KB;
+    p.nks = p.split_steps ? 3 * p.split_steps : (hi_only ? ld16 * 2 / KB : lda_bytes / KB);
     p.nq_out = nq;
     p.k = k;
     p.thr = thr;
     // one query tile of 16-bit operands and enough rows to keep every CU streaming: the ring kernel
+    // (a 256-row query tile against 128 corpus rows, the shape whose three stages still fit in LDS, was measured
+    // slower than the two-stage 256 x 256 kernel: 64 x 64 wave tiles read as many LDS bytes per MFMA as the pipe retires)
     const int stream_max = 128;
     bool stream = kdt != HVS_F32 && nA <= stream_max && row_end - row_begin >= 256 * 256;
     if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= stream_max && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
     if (stream) {
         const int bm = nA <= 32 ? 32 : (nA <= 64 ? 64 : 128);
+        const int bn = 256;
         // split copy: up to 64 rows both query slabs ride in a stage -- (A hi, A lo | X hi) steps, then (A hi | X lo) steps;
         // two query images of 128 rows would leave no room for a third stage, so that tile keeps the three-product order
         const bool dual = p.split_steps != 0 && bm <= 64;
         if (dual) p.nks = 2 * p.split_steps;
         p.cap = CAND_MAX;
         p.QT = 1;
-        p.T = (row_end - row_begin + 255) / 256;
+        p.T = (row_end - row_begin + bn - 1) / bn;
         p.S = (int)(p.T < 256 ? p.T : 256);
         p.dbg = 0;
         const int grid = p.S;
@@ -1060,7 +1073,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, p));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
         HVS_TRY(hvs_prof_begin(idx));
-        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, p.S, k, d_dist, d_ids, d_count));
+        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, p.S, k, d_dist, d_ids, d_count, hi_only));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
         int h_overflow = 0;
         HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
@@ -1116,7 +1129,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, p)));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
     HVS_TRY(hvs_prof_begin(idx));
-    HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count));
+    HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count, hi_only));
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     int h_overflow = 0;
     HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
@@ -1129,5 +1142,132 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
                 h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
     }
     HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 tables, small k: filter on the hi slabs, exact scores for the candidates
+// ---------------------------------------------------------------------------------------------
+// The three products of the split route buy 22-bit operands for every one of the nq x rows scores, of which k per
+// query are kept.  One product over the hi slabs alone gives every similarity to within a known bound:
+//     q s_q = qh + ql, x s_x = xh + xl with |ql_i| <= 2^-11 |q s_q|_i, |xl_i| <= 2^-11 |x s_x|_i (fp16 rounding), so
+//     |q.x s_q s_x - qh.xh| <= sum |qh_i xl_i| + |ql_i xh_i| + |ql_i xl_i| <= 2^-10 (1 + 2^-10) |q s_q| |x s_x|,
+// i.e. 9.78e-4 of similarity, plus the fp32 accumulation of n exact products (<= n 2^-24 whatever the order) and
+// three roundings of the distance formula.  (Elements more than 2^27 below a row's largest are fp16-subnormal after
+// scaling and err by 2^-25 absolutely, which is below 2^-38 sqrt(n) of the row's norm.)
+// So: pass 1 keeps the kc > k rows of smallest approximate distance below thr + eps; pass 2 scores those rows from
+// the fp32 rows with fp32 FMAs, applies thr, orders them by (distance, row position) and keeps k.  A row outside
+// the candidate list has approximate distance >= a_last (the list's largest), hence exact distance >= a_last - eps:
+// the k kept are THE k smallest whenever the k-th exact distance lies below a_last - eps (or the list was not cut
+// at all, or a_last - eps >= thr).  A query for which none of this holds is flagged and searched again by a route
+// that scores every row in full -- the result is the exact top-k in every case, what changes is the time.
+__global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ rows, int ld, const float *__restrict__ inv_norm,
+                                                       const int64_t *__restrict__ ids, const float *__restrict__ q,
+                                                       const float *__restrict__ q_inv, int fold, const float *__restrict__ cand_dist,
+                                                       const int64_t *__restrict__ cand_pos, const int32_t *__restrict__ cand_cnt, int kc,
+                                                       int k, float thr, float eps, float *__restrict__ out_dist,
+                                                       int64_t *__restrict__ out_ids, int32_t *__restrict__ out_count,
+                                                       int32_t *__restrict__ redo) {
+    __shared__ uint64_t keys[MFMA_MAX_K], sorted[MFMA_MAX_K];
+    const int qi = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_c = cand_cnt[qi];
+    for (int c = wave; c < kc; c += 4) {
+        uint64_t key = HVS_KEY_EMPTY;
+        if (c < n_c) {
+            const int64_t pos = cand_pos[(size_t)qi * kc + c];
+            const float *x = rows + (size_t)pos * ld;
+            const float inv_x = inv_norm[pos];
+            float best = __builtin_nanf("");
+            for (int j = 0; j < fold; j++) {
+                const float *e = q + ((size_t)qi * fold + j) * ld;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                for (int i = lane * 4; i < ld; i += 256) {  // ld is a multiple of 4, pad columns are zero on both sides
+                    const float4 a = *reinterpret_cast<const float4 *>(x + i);
+                    const float4 b = *reinterpret_cast<const float4 *>(e + i);
+                    s0 = fmaf(a.x, b.x, s0);
+                    s1 = fmaf(a.y, b.y, s1);
+                    s2 = fmaf(a.z, b.z, s2);
+                    s3 = fmaf(a.w, b.w, s3);
+                }
+                float sum = (s0 + s1) + (s2 + s3);
+                for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                best = fminf(best, hvs_cos_dist(sum, inv_x, q_inv[qi * fold + j]));  // LEAST: NaN only if every term is
+            }
+            if (best < thr) key = hvs_make_key(hvs_ord(best), (uint32_t)pos);
+        }
+        if (lane == 0) keys[c] = key;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < kc) {  // rank by counting: kc <= 128 keys, distinct wherever they are not empty
+        const uint64_t me = keys[t];
+        int rank = 0;
+        for (int i = 0; i < kc; i++) {
+            const uint64_t o = keys[i];
+            rank += (o < me || (o == me && i < t)) ? 1 : 0;
+        }
+        sorted[rank] = me;
+    }
+    __syncthreads();
+    if (t < k) {
+        const uint64_t key = sorted[t];  // k <= kc
+        const bool have = key != HVS_KEY_EMPTY;
+        out_dist[(size_t)qi * k + t] = have ? hvs_unord((uint32_t)(key >> 32)) : __builtin_inff();
+        out_ids[(size_t)qi * k + t] = have ? ids[(uint32_t)key] : -1;
+    }
+    if (t == 0) {
+        int n_valid = 0;
+        while (n_valid < kc && sorted[n_valid] != HVS_KEY_EMPTY) n_valid++;
+        out_count[qi] = n_valid < k ? n_valid : k;
+        bool ok = true;
+        if (n_c >= kc) {  // the list was cut at kc
+            const float bound = cand_dist[(size_t)qi * kc + kc - 1] - eps;  // no row outside the list is closer than this
+            const bool proven = n_valid >= k && hvs_unord((uint32_t)(sorted[k - 1] >> 32)) + 2e-6f < bound;
+            ok = proven || bound >= thr;
+        }
+        redo[qi] = ok ? 0 : 1;
+    }
+}
+
+// *used = false: the route does not apply (k too large for a useful candidate list, or no split copy) and nothing
+// was written.
+int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                       const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
+                       int32_t *d_count, bool *used) {
+    *used = false;
+    if (idx->dtype != HVS_F32 || k > MFMA_MAX_K / 4 || fold > 4 || getenv("HVS_NO_SPLIT") || getenv("HVS_NO_FILTER")) return 0;
+    bool have_split = false;
+    HVS_TRY(hvs_split_ensure(idx, &have_split));
+    if (!have_split) return 0;
+    const int kc = 4 * k < 32 ? 32 : 4 * k;  // candidates per query
+    const int ld16 = (idx->dim + 63) / 64 * 64;
+    const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_pos = up((size_t)nq * kc * 4), o_cnt = o_pos + up((size_t)nq * kc * 8), o_redo = o_cnt + up((size_t)nq * 4);
+    void *ws = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 7, o_redo + up((size_t)nq * 4), &ws));
+    float *c_dist = (float *)ws;
+    int64_t *c_pos = (int64_t *)((char *)ws + o_pos);
+    int32_t *c_cnt = (int32_t *)((char *)ws + o_cnt), *d_redo = (int32_t *)((char *)ws + o_redo);
+    HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, kc, group_filter, d_mask, thr + eps, row_begin, row_end, c_dist, c_pos, c_cnt, 3));
+    HVS_TRY(hvs_prof_begin(idx));
+    rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
+                                                c_cnt, kc, k, thr, eps, d_dist, d_ids, d_count, d_redo);
+    HVS_HIP(hipGetLastError());
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+    std::vector<int32_t> redo(nq);
+    HVS_HIP(hipMemcpyAsync(redo.data(), d_redo, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    int n_redo = 0;
+    for (int i = 0; i < nq; i++) n_redo += redo[i] != 0;
+    *used = true;
+    if (n_redo == 0) return 0;
+    if (n_redo > 8 && n_redo > nq / 64)  // many unproven lists (near-duplicate rows): score the whole batch in full
+        return hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, 1);
+    for (int i = 0; i < nq; i++)
+        if (redo[i])
+            HVS_TRY(hvs_search_scan(idx, d_q + (size_t)i * fold * idx->ld, d_qinv + (size_t)i * fold, 1, fold, k, group_filter, d_mask, thr,
+                                    row_begin, row_end, d_dist + (size_t)i * k, d_ids + (size_t)i * k, d_count + i));
     return 0;
 }

@@ -73,8 +73,9 @@ struct hvs_index {
     int64_t split_cap = 0, split_n = 0;
     bool split_failed = false;  // device memory did not allow the copy
 
-    hvs_workspace ws[7];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
-                          // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search
+    hvs_workspace ws[8];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
+                          // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,
+                          // 7 candidates of the filter pass (hvs_search_rescore)
 
     bool profiling = false;
     double prof_ms[HVS_PROF_COUNT] = {0};

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restr
 
 template <int KL>
 static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
-                           int64_t *d_ids, int32_t *d_count) {
+                           int64_t *d_ids, int32_t *d_count, bool positions) {
     uint64_t *in = bufA, *out = bufB;
     while (P > MERGE_FAN) {
         const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
@@ -588,19 +588,20 @@ static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int n
         uint64_t *t = in; in = out; out = t;
         P = P2;
     }
-    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, idx->ids, d_dist, d_ids, d_count);
+    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, positions ? nullptr : idx->ids, d_dist, d_ids, d_count);
     HVS_HIP(hipGetLastError());
     return 0;
 }
 
-// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys
+// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys.
+// positions: d_ids receives row positions instead of external ids
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
-                     int64_t *d_ids, int32_t *d_count) {
-    if (k <= 64) return reduce_lists_kl<1>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
-    if (k <= 128) return reduce_lists_kl<2>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
-    if (k <= 256) return reduce_lists_kl<4>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
-    if (k <= 512) return reduce_lists_kl<8>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
-    return reduce_lists_kl<16>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count);
+                     int64_t *d_ids, int32_t *d_count, bool positions) {
+    if (k <= 64) return reduce_lists_kl<1>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count, positions);
+    if (k <= 128) return reduce_lists_kl<2>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count, positions);
+    if (k <= 256) return reduce_lists_kl<4>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count, positions);
+    if (k <= 512) return reduce_lists_kl<8>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count, positions);
+    return reduce_lists_kl<16>(idx, bufA, bufB, nq, P, k, d_dist, d_ids, d_count, positions);
 }
 
 // ---- query preparation --------------------------------------------------------------------------
@@ -782,7 +783,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_SCAN));
         HVS_TRY(hvs_prof_begin(idx));
         HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nqo, P, k, d_dist + (size_t)q0 * k,
-                                 d_ids + (size_t)q0 * k, d_count + q0));
+                                 d_ids + (size_t)q0 * k, d_count + q0, false));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     }
     return 0;
@@ -791,6 +792,9 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
                     int64_t *d_ids, int32_t *d_count, int split_mode);
+int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                       const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
+                       int32_t *d_count, bool *used);
 bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k);
 
 // ---- C ABI --------------------------------------------------------------------------------------
@@ -803,7 +807,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     HVS_REQUIRE(queries && out_dist && out_ids && out_count, "hvs_search: NULL argument");
     HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_search: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
     HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_search: k %d not in [1, %d]", k, HVS_MAX_K);
-    HVS_REQUIRE(algo >= HVS_ALGO_AUTO && algo <= HVS_ALGO_MFMA_F32, "hvs_search: unknown algo %d", algo);
+    HVS_REQUIRE(algo >= HVS_ALGO_AUTO && algo <= HVS_ALGO_MFMA_SPLIT, "hvs_search: unknown algo %d", algo);
     if (row_end < 0 || row_end > idx->n) row_end = idx->n;
     if (row_begin < 0) row_begin = 0;
     if (row_begin > row_end) row_begin = row_end;
@@ -836,7 +840,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     }
 
     bool use_mfma = false;
-    if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32) {
+    if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32 || algo == HVS_ALGO_MFMA_SPLIT) {
         HVS_REQUIRE(hvs_mfma_supported(idx, nq, fold, k), "hvs_search: the MFMA path does not support this shape (dtype %d, dim %d, fold %d, k %d)", idx->dtype, idx->dim, fold, k);
         use_mfma = true;
     } else if (algo == HVS_ALGO_AUTO) {
@@ -853,11 +857,20 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         // empty range: counts 0, +inf / -1 entries
         use_mfma = false;
     }
-    if (use_mfma)
+    if (use_mfma) {
         // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy if it exists or from 16 embeddings on
-        HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
-                                algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_MFMA ? 1 : 2)));
-    else
+        const int split_mode = algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_AUTO ? 2 : 1);
+        // ... and where the split copy is in use, small k first tries one product instead of three: a filter pass over
+        // the hi slabs alone, then exact fp32 scores of its candidates (MFMA_SPLIT keeps the three products)
+        bool done = false;
+        if (idx->dtype == HVS_F32 && (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_AUTO) &&
+            (algo == HVS_ALGO_MFMA || nq_total >= 16 || (idx->split && idx->split_n == idx->n)))
+            HVS_TRY(hvs_search_rescore(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids,
+                                       d_count, &done));
+        if (!done)
+            HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                    split_mode));
+    } else
         HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
 
     if (!on_device) {

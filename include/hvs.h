@@ -40,10 +40,14 @@ enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
  * (16-bit) embeddings.  MFMA: batched contraction on the matrix cores; for fp32 rows it runs on the
  * 16-bit pipe over a split copy of the rows (two fp16 slabs per row, three products, fp32-grade
  * scores; the copy doubles the table's device memory and is built on first use) and falls back to the
- * fp32 MFMA kernel when memory does not allow the copy.  MFMA_F32: the fp32 MFMA kernel, no copy.
+ * fp32 MFMA kernel when memory does not allow the copy.  For k <= 32 the split copy is first used as a
+ * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k best candidates per
+ * query are scored again from the fp32 rows in fp32, and a query whose k-th exact score does not clear the
+ * bound of the rows left out is searched again in full -- the exact top-k either way.  MFMA_SPLIT: the
+ * three products for every score, no filter.  MFMA_F32: the fp32 MFMA kernel, no copy.
  * AUTO picks by batch size.
  */
-enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F32 = 3 };
+enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F32 = 3, HVS_ALGO_MFMA_SPLIT = 4 };
 
 /* counters readable through hvs_profile_get */
 enum { HVS_PROF_SCAN = 0, HVS_PROF_MFMA_SEARCH = 1, HVS_PROF_KMEANS_ASSIGN = 2, HVS_PROF_KMEANS_UPDATE = 3,

@@ -46,11 +46,14 @@ def test_mfma_search_matches_oracle(hvs, n, d, dtype):
         d2, i2, c2 = idx.search(q[:8], k=k, algo="scan")
         np.testing.assert_array_equal(c2, cnt[:8])
         np.testing.assert_allclose(d2, dist[:8], atol=2e-6)
-        if dtype == "f32":  # "mfma" ran on the split copy (16-bit pipe); the fp32 MFMA kernel is the third route
-            d3, i3, c3 = idx.search(q, k=k, algo="mfma_f32")
-            _check_all(rows, q, 1, k, d3, i3, c3, label=f"mfma_f32 n={n} d={d} nq={nq} k={k}", storage=dtype)
-            np.testing.assert_array_equal(c3, cnt)
-            np.testing.assert_allclose(d3, dist, atol=2e-6)
+        if dtype == "f32":
+            # "mfma" ran on the split copy (16-bit pipe): as a filter with exact fp32 scores for the candidates up to
+            # k = 32, all three products beyond; those three products for every k and the fp32 MFMA kernel are two more routes
+            for other in ("mfma_f32", "mfma_split"):
+                d3, i3, c3 = idx.search(q, k=k, algo=other)
+                _check_all(rows, q, 1, k, d3, i3, c3, label=f"{other} n={n} d={d} nq={nq} k={k}", storage=dtype)
+                np.testing.assert_array_equal(c3, cnt)
+                np.testing.assert_allclose(d3, dist, atol=2e-6)
     idx.close()
 
 
@@ -82,16 +85,17 @@ def test_split_copy_keeps_fp32_grade_scores(hvs):
     where = rng.permutation(n)[:50]
     idx.update(where, new)                                      # overwritten rows invalidate it
     rows[where] = new
-    for k in (1, 10, 100):
-        dist, ids, cnt = idx.search(q, k=k, algo="mfma")
-        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"split k={k}")
-        dm = parity.distance_matrix(rows, q, "f32")
+    dm = parity.distance_matrix(rows, q, "f32")
+    for k, algo in ((1, "mfma_split"), (10, "mfma_split"), (100, "mfma_split"), (1, "mfma"), (10, "mfma"), (32, "mfma")):
+        dist, ids, cnt = idx.search(q, k=k, algo=algo)  # "mfma" with k <= 32: hi slabs as a filter, exact fp32 rescoring
+        _check_all(rows, q, 1, k, dist, ids, cnt, label=f"{algo} k={k}")
         for i in range(q.shape[0]):
             c = int(cnt[i])
             assert np.abs(dist[i, :c] - dm[i, ids[i, :c]]).max() < 2e-6, f"q={i}"
         d3, i3, c3 = idx.search(q, k=k, algo="mfma_f32")
         np.testing.assert_array_equal(c3, cnt)
         np.testing.assert_allclose(d3, dist, atol=2e-6)
+    dist, ids, cnt = idx.search(q, k=10, algo="mfma")
     assert ids[2, 0] == 700 and dist[2, 0] < 2e-6 and ids[3, 0] == 1200 and dist[3, 0] < 2e-6
     # fold over the split path, and the auto dispatch (from 16 embeddings on fp32 rows take it)
     dist, ids, cnt = idx.search(q, k=10, fold=3, algo="mfma")
@@ -135,7 +139,7 @@ def test_mfma_fold_threshold_filters(hvs, fold, dtype):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype,algo", [("f32", "mfma_f32"), ("f32", "mfma"), ("bf16", "mfma")])
+@pytest.mark.parametrize("dtype,algo", [("f32", "mfma_f32"), ("f32", "mfma"), ("f32", "mfma_split"), ("bf16", "mfma")])
 def test_filtered_batch_runs_over_compacted_rows(hvs, dtype, algo):
     """A selective filter makes the batched path contract over a dense copy of the live rows; the answer
     must be the one the in-epilogue filter gives (same keys, ties included) and the oracle's."""
@@ -272,4 +276,61 @@ def test_kmeans_sums_are_reproducible_and_cover_small_k(hvs):
         _, exp_sums, exp_counts = kmeans_oracle.update(rows[live], a1[live], cent)
         np.testing.assert_array_equal(c1, exp_counts)
         np.testing.assert_allclose(s1, exp_sums, rtol=1e-4, atol=1e-3)
+    idx.close()
+
+
+def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
+    """fp32 table, k <= 32: the hi-slab filter keeps 4 k candidates per query and the answer stands only if the k-th
+    exact distance clears the bound of the rows left out.  Clouds of near-duplicates around a query defeat that
+    bound (hundreds of rows within 1e-4 of each other, the filter errs by up to 1e-3): such queries must come back
+    exact all the same -- searched again one by one when they are few, as a whole batch when they are many."""
+    from hirag_prod_amd import _lib
+
+    rng = np.random.default_rng(31337)
+    n, d = 30_000, 256
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal((3, d)).astype(np.float32)
+    for c in range(3):  # 400 rows within ~3e-5 (cosine distance) of each centre, distinct from one another
+        rows[1000 * (c + 1) : 1000 * (c + 1) + 400] = centre[c] + 8e-3 * rng.standard_normal((400, d)).astype(np.float32)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    q = rng.standard_normal((200, d)).astype(np.float32)
+    q[5], q[77] = centre[0], centre[2]
+    dm = parity.distance_matrix(rows, q, "f32")
+
+    def run(queries, k, **kw):
+        idx.search(queries, k=k, algo="mfma", **kw)
+        idx.profile(True)
+        idx.profile_reset()
+        out = idx.search(queries, k=k, algo="mfma", **kw)
+        scans, full = idx.profile_get(_lib.HVS_PROF_SCAN)[1], idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)[1]
+        idx.profile(False)
+        return out, scans, full
+
+    # two unproven queries out of 200: each searched again alone
+    (dist, ids, cnt), scans, full = run(q, 10)
+    assert 2 <= scans <= 8 and full == 1  # (a random query may have a cloud among its nearest rows too)
+    for i in range(200):
+        parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, label=f"few q={i}")
+    # the same with a threshold that cuts inside the cloud and a row range
+    thr = float(np.sort(dm[5])[25])
+    (dist, ids, cnt), scans, full = run(q, 32, max_distance=thr, row_begin=500, row_end=25_000)
+    keep = np.zeros(n, bool)
+    keep[500:25_000] = True
+    for i in range(200):
+        parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 32, threshold=thr, keep=keep, label=f"thr q={i}")
+    # every query inside a cloud: the whole batch is searched again with all three products
+    qc = (centre[rng.integers(0, 3, 64)] + 1e-3 * rng.standard_normal((64, d))).astype(np.float32)
+    (dist, ids, cnt), scans, full = run(qc, 10)
+    assert scans == 0 and full == 2
+    dmc = parity.distance_matrix(rows, qc, "f32")
+    for i in range(64):
+        parity.check_topk(dist[i], ids[i], cnt[i], dmc[i], 10, label=f"many q={i}")
+    # nothing to prove when the candidate list was not cut: fewer live rows than candidates
+    (dist, ids, cnt), scans, full = run(q[:20], 10, row_begin=1000, row_end=1030)
+    assert scans == 0 and full == 1
+    keep = np.zeros(n, bool)
+    keep[1000:1030] = True
+    for i in range(20):
+        parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, keep=keep, label=f"short q={i}")
     idx.close()

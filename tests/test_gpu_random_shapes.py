@@ -24,6 +24,7 @@ def hvs():
 FIXED = [  # (dim, rows, query groups, fold, k)
     (1, 300, 5, 1, 3), (3, 70, 2, 2, 10), (63, 1000, 33, 1, 10), (64, 129, 65, 1, 7), (65, 2049, 9, 3, 20),
     (127, 31, 40, 1, 40), (129, 5000, 17, 4, 128), (200, 4097, 129, 1, 1), (777, 2500, 6, 2, 50),
+    (96, 3000, 256, 1, 10), (130, 700, 100, 2, 100), (50, 260, 60, 3, 128),  # 129 - 256 A rows
 ]
 
 
@@ -39,7 +40,7 @@ def _cases():
 @pytest.mark.parametrize("stream", ["auto", "ring"])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_random_shapes_all_routes(hvs, dtype, stream, monkeypatch):
-    if stream == "ring":  # up to 128 embeddings: the single-query-tile ring kernel, whatever the row count
+    if stream == "ring":  # up to 128 A rows: the single-query-tile ring kernel, whatever the row count
         monkeypatch.setenv("HVS_STREAM", "1")
     rng = np.random.default_rng(7)
     for dim, n, nq, fold, k in _cases():
@@ -58,7 +59,7 @@ def test_random_shapes_all_routes(hvs, dtype, stream, monkeypatch):
         dm = parity.distance_matrix(rows, q, dtype)
         for gf, thr in ((-1, math.inf), (1, 1.05)):
             keep = keep_all & ((groups == gf) if gf >= 0 else True)
-            routes = ["scan", "mfma"] + (["mfma_f32"] if dtype == "f32" else [])
+            routes = ["scan", "mfma"] + (["mfma_f32", "mfma_split"] if dtype == "f32" else [])
             if fold > 4:
                 routes = ["scan"]
             for algo in routes:
