@@ -11,11 +11,14 @@ the per-rank top-10 lists is merged on every rank.  The corpus is synthetic, gen
 counter-based generator before the timed region.
 
 The timed path computes in fp32 end to end (v_mfma_f32_32x32x2_f32, algo "mfma_f32").  The library's
-default for such batches is faster: it contracts a [hi | lo] fp16 split copy of the same fp32 rows
-on the 16-bit matrix pipe (three products per element, fp32 accumulation, scores within ~1e-8 of
-exact arithmetic).  That route is timed after the headline, on the same resident corpus and the
-same queries, and reported under "aux" -> "split_f16x3"; it is not the headline `value` because its
-products are formed from 16-bit operands.
+own choices for such batches are faster and are timed after the headline, on the same resident corpus
+and the same queries, under "aux": "split_f16x3" contracts a [hi | lo] fp16 split copy of the same
+fp32 rows on the 16-bit matrix pipe (three products per element, fp32 accumulation, scores within
+~1e-8 of exact arithmetic); "filter_f16_rescore_f32" (what algo "auto" / "mfma" run for k <= 32) uses
+the hi slabs alone as a filter with a proven error bound, scores 4 k candidates per query again from
+the fp32 rows in fp32 and searches a query again in full when the bound does not prove its list --
+the same ids as the fp32 kernel.  Neither is the headline `value`, because their matrix products are
+formed from 16-bit operands.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (mfma_search_kernel) against
 the dense fp32 MFMA peak: algorithmic flops = 2 * queries * shard rows * dim per launch, divided
