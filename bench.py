@@ -295,6 +295,25 @@ def main():
             filt["queries_searched_again_in_full"] = int(redone)  # scan launches: one per query whose list was not proven
             result["aux"]["filter_f16_rescore_f32"] = filt
 
+        # one query at a time, left to the library: with the split copy in place it streams the hi slabs (half the bytes
+        # of the fp32 rows) as a filter and scores the candidates exactly
+        d_scan, i_scan, _ = searcher.search(q1, TOPK, algo="scan")
+        for _ in range(3):
+            searcher.search(q1, TOPK)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            d_auto, i_auto, _ = searcher.search(q1, TOPK)
+        torch.cuda.synchronize()
+        e4 = time.perf_counter() - t0
+        if rank == 0:
+            result["aux"]["single_query_auto"] = {
+                "qps": 20 / e4, "ms_per_query": e4 / 20 * 1e3,
+                "fp32_row_bytes_per_s_over_hbm_peak": (hi - lo) * DIM * 4 / (e4 / 20) / (HBM_PEAK_GBS * 1e9),
+                "ids_equal_to_scan": float((i_auto == i_scan).float().mean().item()),
+                "max_abs_score_diff_vs_scan": float((d_auto - d_scan).abs().max().item()),
+            }
+
         # mid-size batch on the same corpus: 64 queries per call (the library's default route: ring kernel on the split copy)
         q64 = queries[:64].contiguous()
         for _ in range(2):

@@ -850,7 +850,13 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         // With the split copy of an fp32 table in place its batches run on the 16-bit pipe too (6.5 ms against 8.9 ms
         // for 8 queries on 4M x 1536).
         const bool f32_pipe = idx->dtype == HVS_F32 && !(idx->split && idx->split_n == idx->n && !getenv("HVS_NO_SPLIT"));
-        const int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
+        int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
+        // A large fp32 table with a current split copy, small k, no WHERE: even one query is better off on the filter
+        // route -- the ring kernel streams the hi slabs, half the bytes the scan has to read, and the candidates are
+        // scored exactly afterwards (10M x 1536: 5.8 ms for up to 64 queries against 8.9 ms for one scan pass)
+        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 32 && group_filter < 0 && !row_mask && row_end - row_begin >= (1 << 20) &&
+            !getenv("HVS_NO_FILTER"))
+            crossover = 1;
         use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);
     }
     if (row_end == row_begin) {
