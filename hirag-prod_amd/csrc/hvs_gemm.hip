@@ -391,7 +391,7 @@ template <class T> __device__ __forceinline__ BlockState block_state(char *smem,
 }
 
 template <int DT, int FOLD, class T>
-__global__ __launch_bounds__(T::GT, (T::GT <= 256 && T::BM < 256) ? 2 : 1) void mfma_search_kernel(SearchParams p) {
+__global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = T::BM, BN = T::BN, STAGE_BYTES = T::STAGE_BYTES, MT = T::MT, NT = T::NT;
@@ -1083,8 +1083,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     }
     // tile shape: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
     bool big = kdt != HVS_F32 && nA > Tile128::BM;
-    if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && (atoi(e) == 256 || atoi(e) == 2564);
-    const bool w4 = big && getenv("HVS_TILE") && atoi(getenv("HVS_TILE")) == 2564;
+    if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
     bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
     if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
     const int bm = big ? Tile256::BM : (small ? Tile64::BM : Tile128::BM), bn = big ? Tile256::BN : (small ? Tile64::BN : Tile128::BN);
@@ -1124,7 +1123,6 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, p)));
     else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, p)));
     else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, p)));
-    else if (kdt == HVS_F16 && w4) HVS_TRY((launch_search<HVS_F16, Tile256W4>(pf, grid, idx->stream, p)));
     else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, p)));
     else if (small) HVS_TRY((launch_search<HVS_BF16, Tile64>(pf, grid, idx->stream, p)));
     else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128>(pf, grid, idx->stream, p)));

@@ -30,7 +30,6 @@ template <int BM_, int BN_, int WM_, int WN_> struct Tile {
 };
 typedef Tile<128, 128, 2, 2> Tile128;
 typedef Tile<256, 256, 2, 4> Tile256;
-typedef Tile<256, 256, 2, 2> Tile256W4;  // experiment: 4 waves of 128 x 128 (accumulators in 256 registers, one wave per SIMD)
 //   Tile64:  64 x 64, 2 waves of 64 x 32, four blocks per CU.  For small batches on the 16-bit pipe: a block always
 //            contracts BM query rows, so up to 64 embeddings cost half the MFMA work of Tile128 and the search
 //            falls back onto the HBM stream.
@@ -167,8 +166,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
         // NEXT slice arrives (A fragments reuse the registers just consumed, X fragments alternate
         // between two sets).  One LDS-DMA piece goes after each half-slice (8 per k-step).
         constexpr int HALF = MT / 2;
-        static_assert(MT % 2 == 0 && PIECES % 8 == 0, "half-slice pipeline: even MT, PIECES / 8 pieces per half-slice");
-        constexpr int PP = PIECES / 8;
+        static_assert(MT % 2 == 0 && PIECES == 8, "half-slice pipeline: even MT, one piece per half-slice");
         f32x4 fa[MT], fb[2][NT];
 #pragma unroll
         for (int t = 0; t < HALF; t++) fa[t] = frag(As, t, h);
@@ -183,8 +181,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = 0; mt < HALF; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-#pragma unroll
-            for (int pp = 0; pp < PP; pp++) dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s * PP + pp);
+            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s);
             __builtin_amdgcn_sched_barrier(0);
             if (s < 3) {
 #pragma unroll
@@ -197,8 +194,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = HALF; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-#pragma unroll
-            for (int pp = 0; pp < PP; pp++) dma_piece<T>(sa, sb, next_stage, next_off, wave, (2 * s + 1) * PP + pp);
+            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s + 1);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
