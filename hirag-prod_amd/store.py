@@ -121,6 +121,62 @@ class _Table:
             setattr(self, name, new)
 
 
+class _SearchCoalescer:
+    """Concurrent ``query`` coroutines of one event loop share launches.
+
+    The reference serves every query with its own SQL statement and runs many at once (25 concurrent
+    queries in ``benchmark/2wiki/eval.py:170-180``).  On the GPU one pass over a table answers a batch
+    at the cost of one query, so requests that agree on (table, workspace/knowledge-base code, top-k,
+    number of folded embeddings, threshold) and carry no row bitmask are stacked into one
+    ``hvs_search`` call.  There is no timer: the first request starts at once (after one turn of the
+    loop), and whatever arrives while a launch is in flight forms the next batch.
+    """
+
+    MAX_BATCH = 1024  # requests per launch
+
+    def __init__(self, run_batch: Callable):
+        self._run_batch = run_batch  # (key, [q, ...]) -> [result, ...]; blocking, runs in a thread
+        self._pending: Dict[tuple, list] = {}
+        self._worker: Optional[asyncio.Task] = None
+        self._loop = None
+        self.launches = 0
+        self.requests = 0
+
+    async def submit(self, key: tuple, q: np.ndarray):
+        loop = asyncio.get_running_loop()
+        if loop is not self._loop:  # a new event loop (tests run one per case): nothing of the old one is left to serve
+            self._loop, self._pending, self._worker = loop, {}, None
+        fut = loop.create_future()
+        self._pending.setdefault(key, []).append((q, fut))
+        if self._worker is None or self._worker.done():
+            self._worker = loop.create_task(self._drain())
+        return await fut
+
+    async def _drain(self):
+        await asyncio.sleep(0)  # the coroutines that are ready right now join the first batch
+        while self._pending:
+            key = next(iter(self._pending))
+            waiting = self._pending[key]
+            batch, rest = waiting[: self.MAX_BATCH], waiting[self.MAX_BATCH :]
+            if rest:
+                self._pending[key] = rest
+            else:
+                del self._pending[key]
+            try:
+                results = await asyncio.to_thread(self._run_batch, key, [q for q, _ in batch])
+                self.launches += 1
+                self.requests += len(batch)
+                for (_, fut), res in zip(batch, results):
+                    if not fut.done():
+                        fut.set_result(res)
+            except BaseException as exc:  # every waiter of the batch sees the failure
+                for _, fut in batch:
+                    if not fut.done():
+                        fut.set_exception(exc)
+                if not isinstance(exc, Exception):
+                    raise
+
+
 class HipVectorStore(BaseVDB):
     """GPU-resident vector store with the reference's ``PGVector`` behaviour on the retrieval path."""
 
@@ -135,6 +191,7 @@ class HipVectorStore(BaseVDB):
         translator: Optional[Callable[[str], Any]] = None,
         index_factory: Optional[Callable[[int, str, int], Any]] = None,
         graph_factory: Optional[Callable[..., Any]] = None,
+        coalesce_queries: bool = True,
     ):
         if vector_type not in ("vector", "halfvec", "bf16"):
             raise ValueError(f"vector_type must be 'vector', 'halfvec' or 'bf16', got {vector_type!r}")
@@ -155,6 +212,7 @@ class HipVectorStore(BaseVDB):
         self._uri_codes: Dict[str, int] = {}
         self._group_codes: Dict[tuple, int] = {}
         self._lock = asyncio.Lock()
+        self._coalescer = _SearchCoalescer(self._search_batch) if coalesce_queries else None
 
     # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
     @classmethod
@@ -465,7 +523,11 @@ class HipVectorStore(BaseVDB):
         if table.index is not None and len(table.rows):
             group_filter, mask, empty = self._row_filter(table, workspace_id, knowledge_base_id, uri_list, require_access)
             if not empty:
-                pairs = await asyncio.to_thread(self._search, table, q, int(topk), group_filter, mask, float(distance_threshold))
+                if self._coalescer is not None and mask is None and q.shape[0] <= _MAX_FOLD:
+                    key = (table_name, int(group_filter), int(topk), int(q.shape[0]), float(distance_threshold))
+                    pairs = await self._coalescer.submit(key, q)
+                else:
+                    pairs = await asyncio.to_thread(self._search, table, q, int(topk), group_filter, mask, float(distance_threshold))
                 want_vec = "vector" in columns_to_select
                 vecs = None
                 if want_vec and pairs:
@@ -482,6 +544,13 @@ class HipVectorStore(BaseVDB):
                     scored.append(payload)
         logger.info(f"[query] Retrieved {len(scored)} records from '{table_name}', elapsed={time.perf_counter() - start:.3f}s")
         return scored
+
+    def _search_batch(self, key: tuple, queries: List[np.ndarray]) -> List[List[tuple]]:
+        """Blocking part of coalesced ``query`` calls: requests with the same key in one launch."""
+        table_name, group_filter, topk, fold, threshold = key
+        index = self.tables[table_name].index
+        dist, ids, cnt = index.search(np.concatenate(queries, axis=0), k=topk, fold=fold, group_filter=group_filter, max_distance=threshold)
+        return [[(int(ids[b][i]), float(dist[b][i])) for i in range(int(cnt[b]))] for b in range(len(queries))]
 
     def _search(self, table: _Table, q: np.ndarray, topk: int, group_filter: int, mask, threshold: float):
         """Blocking part of ``query``: one fused LEAST-fold search (or several for > 8 embeddings)."""

@@ -433,5 +433,50 @@ async def scenario_compact_and_snapshot(store, load_store, storage, directory):
     again.close()
 
 
+async def scenario_concurrent_queries(store, storage):
+    """Many ``query`` coroutines in flight at once (the reference's evaluation runs 25): they share launches, and
+    every caller gets what it would have got alone -- different tables, workspaces, k, fold and thresholds mixed."""
+    await store._init_vdb(embedding_dimension=DIM)
+    n = 300
+    props = [chunk_props(i, ws="ws1" if i % 3 else "ws2") for i in range(n)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts, props, "Chunks")
+    ws = np.array([p["workspaceId"] for p in props])
+    calls = []
+    for j in range(40):
+        w = "ws1" if j % 4 else "ws2"
+        qs = [f"text {w} kb1 {j}"] if j % 3 else [f"text {w} kb1 {j}", f"variant {j}", f"other {j}"]
+        k = 10 if j % 5 else 7
+        thr = 1.3 if j % 2 else 0.9
+        calls.append((qs, w, k, thr))
+    uris = np.array([p["uri"] for p in props])
+    calls.append((["text ws1 kb1 5"], "ws1", 10, 1.3, [props[5]["uri"]]))  # a bitmask filter: served alone
+    results = await asyncio.gather(*[
+        store.query(c[0], c[1], "kb1", "Chunks", topk=c[2], distance_threshold=c[3], uri_list=c[4] if len(c) > 4 else None) for c in calls])
+    for c, res in zip(calls, results):
+        keep = ws == c[1]
+        if len(c) > 4:
+            keep = keep & np.isin(uris, c[4])
+        idx, dist = expected_hits(texts, keep, c[0], c[2], c[3], storage)
+        same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+    co = store._coalescer
+    assert co.requests == 40 and co.launches < 40  # 16 distinct (workspace, k, fold, threshold) keys at most
+    # a failing launch reaches every waiter of its batch and leaves the queue usable
+    table = store.tables["Chunks"]
+    real = table.index
+
+    class Boom:
+        def search(self, *a, **kw):
+            raise RuntimeError("launch failed")
+
+    table.index = Boom()
+    failed = await asyncio.gather(*[store.query("x", "ws1", "kb1", "Chunks") for _ in range(3)], return_exceptions=True)
+    assert all(isinstance(f, RuntimeError) for f in failed)
+    table.index = real
+    res = await store.query("text ws1 kb1 4", "ws1", "kb1", "Chunks", distance_threshold=1.3)
+    idx, dist = expected_hits(texts, ws == "ws1", ["text ws1 kb1 4"], 10, 1.3, storage)
+    same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+
+
 def run(coro):
     return asyncio.run(coro)

@@ -37,6 +37,13 @@ def test_store_load_rows_gpu(vector_type, storage):
     b.close()
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
+def test_store_concurrent_queries_share_launches_gpu(vector_type, storage):
+    s = _store(vector_type)
+    store_cases.run(store_cases.scenario_concurrent_queries(s, storage))
+    s.close()
+
+
 def test_store_many_embeddings_gpu():
     s = _store("halfvec")
     store_cases.run(store_cases.scenario_many_embeddings(s, "f16"))

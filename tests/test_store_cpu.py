@@ -29,6 +29,10 @@ def test_store_load_rows():
     store_cases.run(store_cases.scenario_load_rows(_store("halfvec"), _store("halfvec"), "f16"))
 
 
+def test_store_concurrent_queries_share_launches():
+    store_cases.run(store_cases.scenario_concurrent_queries(_store("halfvec"), "f16"))
+
+
 def test_store_many_embeddings():
     store_cases.run(store_cases.scenario_many_embeddings(_store("halfvec"), "f16"))
 
