@@ -620,6 +620,18 @@ extern "C" int hvs_index_deleted_count(hvs_index *idx, int64_t *out_rows) {
     return 0;
 }
 
+extern "C" int hvs_index_prepare(hvs_index *idx, int *out_ready) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_prepare: idx is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    bool ok = false;
+    if (idx->dtype == HVS_F32 && idx->n > 0 && !getenv("HVS_NO_SPLIT")) {
+        HVS_TRY(hvs_split_ensure(idx, &ok));
+        HVS_HIP(hipStreamSynchronize(idx->stream));
+    }
+    if (out_ready) *out_ready = ok ? 1 : 0;
+    return 0;
+}
+
 extern "C" int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64_t *ids, int32_t *group_codes,
                                 uint8_t *deleted) {
     HVS_REQUIRE(idx != nullptr, "hvs_index_export: idx is NULL");

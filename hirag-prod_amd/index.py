@@ -309,6 +309,15 @@ class HvsIndex:
         check(self._lib.hvs_index_deleted_count(self._h, ctypes.byref(n)))
         return n.value
 
+    def prepare(self) -> bool:
+        """Build (or extend) the search-side copy of an fp32 table now instead of on the first batched search; True
+        when it is in place.  With it, searches with k <= 32 -- one query at a time on a large table included --
+        stream half the bytes and score their candidates exactly afterwards.  No-op (False) for 16-bit tables."""
+        ready = ctypes.c_int(0)
+        with self._lock:
+            check(self._lib.hvs_index_prepare(self._h, ctypes.byref(ready)))
+        return bool(ready.value)
+
     def compact(self, renumber_ids: bool = False) -> int:
         """Drop deleted rows and close the gaps (order kept); returns the new row count.  Row
         positions change: position i afterwards is the i-th live row before.  Ids move with their

@@ -716,6 +716,17 @@ class HipVectorStore(BaseVDB):
             out.append(rec)
         return out
 
+    async def prepare(self, table_name: Optional[str] = None) -> Dict[str, bool]:
+        """After a bulk load of a ``vector`` (fp32) store: build the tables' search-side copies now rather than on the
+        first batched query, so that even single queries stream half the bytes (``HvsIndex.prepare``).  Returns
+        ``{table: ready}``; 16-bit stores need none and report False."""
+        out: Dict[str, bool] = {}
+        for name in ([table_name] if table_name else list(self.tables)):
+            table = self.get_model(name)
+            if table.index is not None and hasattr(table.index, "prepare"):
+                out[name] = bool(await asyncio.to_thread(table.index.prepare))
+        return out
+
     # -- compaction and snapshots (the table outlives deletes and restarts) --------------------------
     async def compact(self, table_name: Optional[str] = None) -> Dict[str, int]:
         """Reclaim the rows ``clean_table`` deleted: tombstoned rows leave HBM and the host lists, the

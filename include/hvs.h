@@ -112,6 +112,16 @@ int hvs_index_deleted_count(hvs_index *idx, int64_t *out_rows);
 int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
 
 /*
+ * Bring the search-side copy of an fp32 table up to date ahead of the first search (it is otherwise built by the
+ * first batched search): the [hi | lo] fp16 split copy that batched searches contract and that searches with
+ * k <= 32, single queries on large tables included, use as a filter before exact fp32 scoring.  The nearest
+ * thing in the reference is the index DDL of PGVector._init_vdb (pgvector.py:704-726): work done once so that
+ * queries are fast.  *out_ready (may be NULL) = 1 when the copy is in place, 0 when the table is 16-bit (no
+ * copy needed) or device memory does not allow it (searches then stay on the fp32 kernels).
+ */
+int hvs_index_prepare(hvs_index *idx, int *out_ready);
+
+/*
  * Copy rows [first, first + n) to HOST buffers, for snapshots: rows as stored
  * (index dtype, n * dim elements, no padding; feeding them back through
  * hvs_index_add with src_dtype = the index dtype reproduces the table bit for

@@ -433,3 +433,37 @@ def test_distance_column_of_many_embeddings(hvs, dtype):
         with pytest.raises(hvs.HvsError):
             idx.distances(np.ones((129, d), np.float32))
         idx.close()
+
+
+def test_prepare_builds_the_search_side_copy(hvs):
+    """``hvs_index_prepare``: an fp32 table gets its split copy ahead of the first search; from then on a single
+    query on a large table takes the filter route (matrix-pipe launch, no scan launch) and returns the oracle's rows."""
+    from hirag_prod_amd import _lib
+
+    n, d = (1 << 20) + 77, 64
+    idx = hvs.HvsIndex(d, "f32")
+    idx.fill_synthetic(n, seed=99)
+    q = po.synth_rows(98, 0, 2, d)
+    rows = po.synth_rows(99, 0, n, d)
+
+    def launches():
+        idx.profile(True)
+        idx.profile_reset()
+        out = idx.search(q[:1], k=10)
+        c = idx.profile_get(_lib.HVS_PROF_SCAN)[1], idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)[1]
+        idx.profile(False)
+        return out, c
+
+    (d0, i0, c0), (scans, mf) = launches()
+    assert scans == 1 and mf == 0
+    assert idx.prepare() is True
+    (d1, i1, c1), (scans, mf) = launches()
+    assert scans == 0 and mf == 1
+    full = parity.full_distances(rows, q[0], "f32")
+    parity.check_topk(d0[0], i0[0], c0[0], full, 10, label="scan")
+    parity.check_topk(d1[0], i1[0], c1[0], full, 10, label="filter route")
+    idx.close()
+    half = hvs.HvsIndex(d, "f16")
+    half.add(rows[:100])
+    assert half.prepare() is False
+    half.close()
