@@ -58,9 +58,15 @@ def test_10m_x_1536_f32_top10(hvs):
     for j in range(4):
         assert sorted(ids[j].tolist()) == sorted(planted_pos[j].tolist())
     _recheck(idx, q[:8], dist[:8], ids[:8], "f32")
-    # "mfma" contracted the [hi | lo] fp16 split copy of the fp32 rows; the fp32 MFMA kernel gives the same rows
+    # "mfma" used the hi slabs of the split copy as a filter and scored 40 candidates per query exactly; the three
+    # products over both slabs and the fp32 MFMA kernel give the same rows
     d1, i1, c1 = idx.search(q, k=k, algo="mfma_f32")
     _same_up_to_ties(d1, i1, dist, ids)
+    d1, i1, c1 = idx.search(q, k=k, algo="mfma_split")
+    _same_up_to_ties(d1, i1, dist, ids)
+    # left to itself the library takes the filter route for a single query on this table too
+    d1, i1, c1 = idx.search(q[9:10], k=k)
+    _same_up_to_ties(d1, i1, dist[9:10], ids[9:10])
     # the streaming scan is an independent kernel: same rows, same order
     d2, i2, c2 = idx.search(q[:4], k=k, algo="scan")
     _same_up_to_ties(d2, i2, dist[:4], ids[:4])
