@@ -853,8 +853,12 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
         // A large fp32 table with a current split copy, small k, no WHERE: even one query is better off on the filter
         // route -- the ring kernel streams the hi slabs, half the bytes the scan has to read, and the candidates are
-        // scored exactly afterwards (10M x 1536: 5.8 ms for up to 64 queries against 8.9 ms for one scan pass)
-        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 32 && group_filter < 0 && !row_mask && row_end - row_begin >= (1 << 20) &&
+        // scored exactly afterwards (10M x 1536: 5.8 ms for up to 64 queries against 8.9 ms for one scan pass).  End to
+        // end the routes cross at about 1.5 GB of fp32 rows (1536 columns: 0.35 / 0.37 ms at 262 144 rows, 0.48 / 0.61 ms
+        // at 524 288, 0.74 / 1.05 ms at 1M); from 2 GB on the filter route is taken.
+        int64_t filter_min_rows = ((int64_t)500 * 1000 * 1000 + idx->ld - 1) / idx->ld;
+        if (const char *e = getenv("HVS_FILTER_MIN_ROWS")) filter_min_rows = atoll(e);
+        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 32 && group_filter < 0 && !row_mask && row_end - row_begin >= filter_min_rows &&
             !getenv("HVS_NO_FILTER"))
             crossover = 1;
         use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);

@@ -435,12 +435,13 @@ def test_distance_column_of_many_embeddings(hvs, dtype):
         idx.close()
 
 
-def test_prepare_builds_the_search_side_copy(hvs):
+def test_prepare_builds_the_search_side_copy(hvs, monkeypatch):
     """``hvs_index_prepare``: an fp32 table gets its split copy ahead of the first search; from then on a single
     query on a large table takes the filter route (matrix-pipe launch, no scan launch) and returns the oracle's rows."""
     from hirag_prod_amd import _lib
 
     n, d = (1 << 20) + 77, 64
+    monkeypatch.setenv("HVS_FILTER_MIN_ROWS", "1000000")  # (by default the route starts at 2 GB of fp32 rows)
     idx = hvs.HvsIndex(d, "f32")
     idx.fill_synthetic(n, seed=99)
     q = po.synth_rows(98, 0, 2, d)
