@@ -334,3 +334,45 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     for i in range(20):
         parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, keep=keep, label=f"short q={i}")
     idx.close()
+
+
+def test_filter_route_on_ladders_of_close_rows(hvs):
+    """Rows at cosine distances delta, 2 delta, 3 delta, ... from a query, for spacings from far below to about the
+    filter's error bound (1e-3): the hi-slab scores cannot order such rows, so the answer is right only if the
+    proof refuses every list it cannot vouch for.  Exact order expected at every spacing (the spacings stay above
+    the tie tolerance), with rows of mixed magnitude."""
+    rng = np.random.default_rng(99)
+    n_fill, d, steps = 6000, 384, 300
+    spacings = (1e-5, 3e-5, 1e-4, 3e-4, 1e-3)
+    rows = [rng.standard_normal((n_fill, d))]
+    q = rng.standard_normal((len(spacings), d))
+    for s, delta in enumerate(spacings):
+        qh = q[s] / np.linalg.norm(q[s])
+        u = rng.standard_normal((steps, d))
+        u -= (u @ qh)[:, None] * qh[None, :]
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        cos = 1.0 - delta * np.arange(1, steps + 1)
+        ladder = cos[:, None] * qh[None, :] + np.sqrt(1.0 - cos * cos)[:, None] * u
+        rows.append(ladder * np.exp(rng.uniform(-3, 3, (steps, 1))))
+    rows = np.concatenate(rows).astype(np.float32)
+    perm = rng.permutation(rows.shape[0])
+    rows = rows[perm]
+    q = q.astype(np.float32)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    dm = parity.distance_matrix(rows, q, "f32")
+    for k in (1, 10, 32):
+        for algo in ("mfma", "auto"):
+            qq = np.tile(q, (4, 1)) if algo == "auto" else q  # 20 embeddings: AUTO takes the matrix pipe
+            dist, ids, cnt = idx.search(qq, k=k, algo=algo)
+            for i in range(qq.shape[0]):
+                full = dm[i % len(spacings)]
+                parity.check_topk(dist[i], ids[i], cnt[i], full, k, label=f"ladder {spacings[i % len(spacings)]} k={k} {algo}")
+                exp = np.argsort(full, kind="stable")[:k]
+                assert ids[i][:k].tolist() == exp.tolist(), f"ladder {spacings[i % len(spacings)]} k={k} {algo}: order"
+    # thresholds that cut a ladder between two rungs
+    for s, delta in enumerate(spacings):
+        thr = float(delta * 7.5)
+        dist, ids, cnt = idx.search(q[s : s + 1], k=32, max_distance=thr, algo="mfma")
+        assert cnt[0] == 7 and ids[0][:7].tolist() == np.argsort(dm[s], kind="stable")[:7].tolist(), f"thr on ladder {delta}"
+    idx.close()
