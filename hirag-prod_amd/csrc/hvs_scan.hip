@@ -497,15 +497,22 @@ __device__ __forceinline__ void wl_load(uint64_t (&a)[KL], const uint64_t *src, 
     }
 }
 
+// the other list, reversed, as the merge below consumes it
 template <int KL>
-__device__ __forceinline__ void wl_merge(uint64_t (&a)[KL], const uint64_t *other, int n, int lane) {
+__device__ __forceinline__ void wl_load_reversed(uint64_t (&b)[KL], const uint64_t *other, int n, int lane) {
     constexpr int N = 64 * KL;
 #pragma unroll
     for (int e = 0; e < KL; e++) {
-        const int i = N - 1 - (e * 64 + lane);  // the other list, reversed
-        const uint64_t b = i < n ? other[i] : HVS_KEY_EMPTY;
-        a[e] = b < a[e] ? b : a[e];
+        const int i = N - 1 - (e * 64 + lane);
+        b[e] = i < n ? other[i] : HVS_KEY_EMPTY;
     }
+}
+
+// a = the 64 KL smallest of a (ascending) and b (a list loaded by wl_load_reversed), ascending
+template <int KL>
+__device__ __forceinline__ void wl_merge(uint64_t (&a)[KL], const uint64_t (&b)[KL], int lane) {
+#pragma unroll
+    for (int e = 0; e < KL; e++) a[e] = b[e] < a[e] ? b[e] : a[e];
 #pragma unroll
     for (int se = KL / 2; se >= 1; se >>= 1) {  // strides 64 * se: register pairs inside a lane
 #pragma unroll
@@ -546,7 +553,17 @@ __global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restr
     const uint64_t *src = in + ((size_t)q * P + first) * k;
     uint64_t a[KL];
     wl_load<KL>(a, src, k, lane);
-    for (int j = 1; j < nl; j++) wl_merge<KL>(a, src + (size_t)j * k, k, lane);
+    // the lists' addresses do not depend on the merges: fetch them a group ahead, so that a wave waits for global
+    // memory once per group instead of once per list
+    constexpr int AHEAD = KL <= 2 ? 8 : (KL <= 4 ? 4 : 2);
+    for (int j0 = 1; j0 < nl; j0 += AHEAD) {
+        uint64_t b[AHEAD][KL];
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) wl_load_reversed<KL>(b[u], src + (size_t)(j0 + u < nl ? j0 + u : j0) * k, j0 + u < nl ? k : 0, lane);
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++)
+            if (j0 + u < nl) wl_merge<KL>(a, b[u], lane);
+    }
     if (!FINAL) {
         uint64_t *o = out_keys + ((size_t)q * P2 + grp) * k;
 #pragma unroll
