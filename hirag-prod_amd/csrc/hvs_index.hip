@@ -179,6 +179,23 @@ int hvs_ws_get(hvs_index *idx, int slot, size_t bytes, void **out) {
     return 0;
 }
 
+int hvs_pinned_get(hvs_index *idx, size_t bytes, void **out) {
+    if (idx->h_pin_bytes < bytes) {
+        if (idx->h_pin) {
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+            HVS_HIP(hipHostFree(idx->h_pin));
+            idx->h_pin = nullptr;
+            idx->h_pin_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        if (want < (64u << 10)) want = 64u << 10;
+        HVS_HIP(hipHostMalloc(&idx->h_pin, want, hipHostMallocDefault));
+        idx->h_pin_bytes = want;
+    }
+    *out = idx->h_pin;
+    return 0;
+}
+
 int hvs_prof_begin(hvs_index *idx) {
     if (!idx->profiling) return 0;
     HVS_HIP(hipEventRecord(idx->ev0, idx->stream));
@@ -411,6 +428,7 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
     hipFree(idx->split);
     hipFree(idx->split_inv);
     for (auto &w : idx->ws) hipFree(w.ptr);
+    if (idx->h_pin) hipHostFree(idx->h_pin);
     hipEventDestroy(idx->ev0);
     hipEventDestroy(idx->ev1);
     hipEventDestroy(idx->tm0);

@@ -77,6 +77,9 @@ struct hvs_index {
                           // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,
                           // 7 candidates of the filter pass (hvs_search_rescore)
 
+    void *h_pin = nullptr;  // pinned host buffer: the results of a search cross to the host in one copy
+    size_t h_pin_bytes = 0;
+
     bool profiling = false;
     double prof_ms[HVS_PROF_COUNT] = {0};
     int64_t prof_launches[HVS_PROF_COUNT] = {0};
@@ -85,6 +88,7 @@ struct hvs_index {
 };
 
 int hvs_ws_get(hvs_index *idx, int slot, size_t bytes, void **out);
+int hvs_pinned_get(hvs_index *idx, size_t bytes, void **out);  // pinned host memory, grown like a workspace
 
 // RAII-less profiling bracket: HVS_PROF_BEGIN(idx) ... launch ... HVS_PROF_END(idx, which)
 int hvs_prof_begin(hvs_index *idx);

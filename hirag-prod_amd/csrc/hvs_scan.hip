@@ -901,10 +901,25 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
 
     if (!on_device) {
-        HVS_HIP(hipMemcpyAsync(out_dist, d_dist, dist_bytes, hipMemcpyDeviceToHost, idx->stream));
-        HVS_HIP(hipMemcpyAsync(out_ids, d_ids, ids_bytes, hipMemcpyDeviceToHost, idx->stream));
-        HVS_HIP(hipMemcpyAsync(out_count, d_count, cnt_bytes, hipMemcpyDeviceToHost, idx->stream));
-        HVS_HIP(hipStreamSynchronize(idx->stream));
+        const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
+        const size_t o_cnt = (o_ids + ids_bytes + 255) & ~(size_t)255;
+        const size_t span = o_cnt + cnt_bytes;  // the three outputs lie in one staging buffer (see above)
+        if (span <= ((size_t)8 << 20)) {
+            // one copy into pinned memory instead of three into pageable buffers: each of those costs about as much
+            // as the scan of a small table
+            void *h = nullptr;
+            HVS_TRY(hvs_pinned_get(idx, span, &h));
+            HVS_HIP(hipMemcpyAsync(h, d_dist, span, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+            memcpy(out_dist, h, dist_bytes);
+            memcpy(out_ids, (const char *)h + o_ids, ids_bytes);
+            memcpy(out_count, (const char *)h + o_cnt, cnt_bytes);
+        } else {
+            HVS_HIP(hipMemcpyAsync(out_dist, d_dist, dist_bytes, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipMemcpyAsync(out_ids, d_ids, ids_bytes, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipMemcpyAsync(out_count, d_count, cnt_bytes, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+        }
     }
     return 0;
 }
