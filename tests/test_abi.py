@@ -34,6 +34,9 @@ def test_constants_match_header():
     assert int(re.search(r"#define HVS_MAX_K (\d+)", text).group(1)) == _lib.HVS_MAX_K
     assert int(re.search(r"#define HVS_MAX_FOLD (\d+)", text).group(1)) == _lib.HVS_MAX_FOLD
     assert int(re.search(r"#define HVS_MAX_DIST_FOLD (\d+)", text).group(1)) == _lib.HVS_MAX_DIST_FOLD
+    algos = dict(re.findall(r"(HVS_ALGO_\w+) = (\d+)", text))
+    assert algos and all(getattr(_lib, name) == int(value) for name, value in algos.items())
+    assert sorted(_lib.ALGO_CODE.values()) == sorted(int(v) for v in algos.values())
 
 
 def test_errors_cross_the_boundary_as_messages():
