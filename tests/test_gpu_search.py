@@ -468,3 +468,58 @@ def test_prepare_builds_the_search_side_copy(hvs, monkeypatch):
     half.add(rows[:100])
     assert half.prepare() is False
     half.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_repeated_small_searches_follow_the_table(hvs, dtype):
+    """The serving pattern: the same shape of search over and over on a small table, through reused workspaces and
+    the pinned result buffer.  Every call must see its own query, and every change to the table (append, overwrite,
+    delete, compaction) must reach the next answer."""
+    rng = np.random.default_rng(12)
+    n, d = 5000, 192
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    idx = _mk(hvs, rows, dtype)
+    groups_live = np.ones(n, bool)
+
+    def check(rows_now, keep, label, reps=5, **kw):
+        for r in range(reps):
+            q = rng.standard_normal((3, d)).astype(np.float32)
+            dist, ids, cnt = idx.search(q, k=10, fold=3, max_distance=1.1, algo="scan", **kw)
+            lo, hi = kw.get("row_begin", 0), kw.get("row_end", -1)
+            kp = keep.copy()
+            kp[:lo] = False
+            if hi >= 0:
+                kp[hi:] = False
+            parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows_now, q, dtype), 10, threshold=1.1, keep=kp,
+                              label=f"{label} rep {r}")
+
+    check(rows, groups_live, "fresh")
+    check(rows, groups_live, "range", row_begin=100, row_end=4000)
+    more = rng.standard_normal((700, d)).astype(np.float32)
+    idx.add(more)
+    rows2 = np.concatenate([rows, more])
+    keep = np.ones(len(rows2), bool)
+    check(rows2, keep, "appended")
+    new = rng.standard_normal((5, d)).astype(np.float32)
+    idx.update(np.arange(5), new)
+    rows2[:5] = new
+    q = np.concatenate([new[:1], new[1:3]])
+    dist, ids, cnt = idx.search(q, k=10, fold=3, max_distance=1.1, algo="scan")
+    assert set(ids[0][:3].tolist()) == {0, 1, 2} and dist[0][2] < 1e-3
+    check(rows2, keep, "overwritten")
+    idx.set_deleted(np.arange(0, len(rows2), 3), True)
+    keep[::3] = False
+    check(rows2, keep, "deleted")
+    idx.compact(renumber_ids=True)
+    check(rows2[keep], np.ones(int(keep.sum()), bool), "compacted")
+    # single queries of other shapes in between, and timing switched on (the ordinary path) and off again
+    for k in (1, 10, 50):
+        q1 = rng.standard_normal((1, d)).astype(np.float32)
+        for _ in range(3):
+            dist, ids, cnt = idx.search(q1, k=k, algo="scan")
+            parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows2[keep], q1[0], dtype), k, label=f"k={k}")
+    idx.profile(True)
+    check(rows2[keep], np.ones(int(keep.sum()), bool), "timed", reps=2)
+    idx.profile(False)
+    check(rows2[keep], np.ones(int(keep.sum()), bool), "again", reps=3)
+    idx.close()
