@@ -1160,7 +1160,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
 // the candidate list has approximate distance >= a_last (the list's largest), hence exact distance >= a_last - eps:
 // the k kept are THE k smallest whenever the k-th exact distance lies below a_last - eps (or the list was not cut
 // at all, or a_last - eps >= thr).  A query for which none of this holds is flagged and searched again by a route
-// that scores every row in full -- the result is the exact top-k in every case, what changes is the time.
+// that scores every row in full (one flagged query: an fp32 scan; several: a batch of their own with all three
+// products) -- the result is the exact top-k in every case, what changes is the time.
 __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ rows, int ld, const float *__restrict__ inv_norm,
                                                        const int64_t *__restrict__ ids, const float *__restrict__ q,
                                                        const float *__restrict__ q_inv, int fold, const float *__restrict__ cand_dist,
@@ -1230,6 +1231,28 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
     }
 }
 
+// the flagged queries of a batch as a batch of their own: embeddings and inverse norms gathered ...
+__global__ void gather_queries_kernel(const float *__restrict__ q, const float *__restrict__ q_inv, const int32_t *__restrict__ list,
+                                      int fold, int ld, float *__restrict__ q_sub, float *__restrict__ q_inv_sub) {
+    const int j = blockIdx.x;
+    const float *src = q + (size_t)list[j] * fold * ld;
+    float *dst = q_sub + (size_t)j * fold * ld;
+    for (int c = threadIdx.x; c < fold * ld; c += blockDim.x) dst[c] = src[c];
+    if (threadIdx.x < fold) q_inv_sub[j * fold + threadIdx.x] = q_inv[list[j] * fold + threadIdx.x];
+}
+
+// ... and their answers put back in their places
+__global__ void scatter_results_kernel(const float *__restrict__ sub_dist, const int64_t *__restrict__ sub_ids,
+                                       const int32_t *__restrict__ sub_cnt, const int32_t *__restrict__ list, int k,
+                                       float *__restrict__ dist, int64_t *__restrict__ ids, int32_t *__restrict__ cnt) {
+    const int j = blockIdx.x, qi = list[j];
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        dist[(size_t)qi * k + i] = sub_dist[(size_t)j * k + i];
+        ids[(size_t)qi * k + i] = sub_ids[(size_t)j * k + i];
+    }
+    if (threadIdx.x == 0) cnt[qi] = sub_cnt[j];
+}
+
 // *used = false: the route does not apply (k too large for a useful candidate list, or no split copy) and nothing
 // was written.
 int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
@@ -1245,8 +1268,15 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_pos = up((size_t)nq * kc * 4), o_cnt = o_pos + up((size_t)nq * kc * 8), o_redo = o_cnt + up((size_t)nq * 4);
+    // behind the candidates: room to search the flagged queries again as a batch of their own (list, embeddings,
+    // inverse norms, outputs), unless that would be a workspace of its own size class
+    const size_t sub_q_bytes = (size_t)nq * fold * idx->ld * 4;
+    const bool sub_ok = sub_q_bytes <= ((size_t)256 << 20);
+    const size_t o_list = o_redo + up((size_t)nq * 4), o_subq = o_list + up((size_t)nq * 4), o_subinv = o_subq + (sub_ok ? up(sub_q_bytes) : 0),
+                 o_subd = o_subinv + up((size_t)nq * fold * 4), o_subi = o_subd + up((size_t)nq * k * 4), o_subc = o_subi + up((size_t)nq * k * 8),
+                 ws_bytes = sub_ok ? o_subc + up((size_t)nq * 4) : o_list;
     void *ws = nullptr;
-    HVS_TRY(hvs_ws_get(idx, 7, o_redo + up((size_t)nq * 4), &ws));
+    HVS_TRY(hvs_ws_get(idx, 7, ws_bytes, &ws));
     float *c_dist = (float *)ws;
     int64_t *c_pos = (int64_t *)((char *)ws + o_pos);
     int32_t *c_cnt = (int32_t *)((char *)ws + o_cnt), *d_redo = (int32_t *)((char *)ws + o_redo);
@@ -1263,11 +1293,29 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     for (int i = 0; i < nq; i++) n_redo += redo[i] != 0;
     *used = true;
     if (n_redo == 0) return 0;
-    if (n_redo > 8 && n_redo > nq / 64)  // many unproven lists (near-duplicate rows): score the whole batch in full
+    if (n_redo == 1 || (!sub_ok && n_redo <= 8)) {  // one exact scan per flagged query
+        for (int i = 0; i < nq; i++)
+            if (redo[i])
+                HVS_TRY(hvs_search_scan(idx, d_q + (size_t)i * fold * idx->ld, d_qinv + (size_t)i * fold, 1, fold, k, group_filter, d_mask, thr,
+                                        row_begin, row_end, d_dist + (size_t)i * k, d_ids + (size_t)i * k, d_count + i));
+        return 0;
+    }
+    if (n_redo == nq || !sub_ok)  // every list unproven (a table of near-duplicates): the whole batch with all three products
         return hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, 1);
+    // the flagged queries as a batch of their own, all three products: one more pass over the rows whatever their number
+    std::vector<int32_t> list;
     for (int i = 0; i < nq; i++)
-        if (redo[i])
-            HVS_TRY(hvs_search_scan(idx, d_q + (size_t)i * fold * idx->ld, d_qinv + (size_t)i * fold, 1, fold, k, group_filter, d_mask, thr,
-                                    row_begin, row_end, d_dist + (size_t)i * k, d_ids + (size_t)i * k, d_count + i));
+        if (redo[i]) list.push_back(i);
+    int32_t *d_list = (int32_t *)((char *)ws + o_list);
+    float *sub_q = (float *)((char *)ws + o_subq), *sub_inv = (float *)((char *)ws + o_subinv), *sub_d = (float *)((char *)ws + o_subd);
+    int64_t *sub_i = (int64_t *)((char *)ws + o_subi);
+    int32_t *sub_c = (int32_t *)((char *)ws + o_subc);
+    HVS_HIP(hipMemcpyAsync(d_list, list.data(), (size_t)n_redo * 4, hipMemcpyHostToDevice, idx->stream));
+    gather_queries_kernel<<<n_redo, 256, 0, idx->stream>>>(d_q, d_qinv, d_list, fold, idx->ld, sub_q, sub_inv);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipStreamSynchronize(idx->stream));  // `list` is pageable host memory
+    HVS_TRY(hvs_search_mfma(idx, sub_q, sub_inv, n_redo, fold, k, group_filter, d_mask, thr, row_begin, row_end, sub_d, sub_i, sub_c, 1));
+    scatter_results_kernel<<<n_redo, 64, 0, idx->stream>>>(sub_d, sub_i, sub_c, d_list, k, d_dist, d_ids, d_count);
+    HVS_HIP(hipGetLastError());
     return 0;
 }

@@ -307,9 +307,9 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
         idx.profile(False)
         return out, scans, full
 
-    # two unproven queries out of 200: each searched again alone
+    # two unproven queries out of 200: searched again as a batch of their own, all three products
     (dist, ids, cnt), scans, full = run(q, 10)
-    assert 2 <= scans <= 8 and full == 1  # (a random query may have a cloud among its nearest rows too)
+    assert scans == 0 and full == 2
     for i in range(200):
         parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, label=f"few q={i}")
     # the same with a threshold that cuts inside the cloud and a row range
@@ -319,6 +319,11 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     keep[500:25_000] = True
     for i in range(200):
         parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 32, threshold=thr, keep=keep, label=f"thr q={i}")
+    # a single unproven query: one exact scan
+    (dist1, ids1, cnt1), scans, full = run(q[:40], 10)
+    assert scans == 1 and full == 1
+    for i in range(40):
+        parity.check_topk(dist1[i], ids1[i], cnt1[i], dm[i], 10, label=f"one q={i}")
     # every query inside a cloud: the whole batch is searched again with all three products
     qc = (centre[rng.integers(0, 3, 64)] + 1e-3 * rng.standard_normal((64, d))).astype(np.float32)
     (dist, ids, cnt), scans, full = run(qc, 10)
