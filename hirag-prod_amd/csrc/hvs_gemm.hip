@@ -1059,7 +1059,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         void *cand = nullptr, *bufB = nullptr;
         const size_t cand_bytes = (size_t)grid * (bm / pf) * p.cap * 8;
         const size_t part_bytes = (size_t)nq * p.S * k * 8;
-        const int P2 = (p.S + 31) / 32;
+        const int P2 = (p.S + MERGE_FAN - 1) / MERGE_FAN;
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
         HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
         void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
@@ -1108,7 +1108,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     void *cand = nullptr, *bufA = nullptr, *bufB = nullptr;
     const size_t cand_bytes = (size_t)grid * groups_per_tile * cap * 8;
     const size_t part_bytes = (size_t)nq * S * k * 8;
-    const int P2 = (S + 31) / 32;
+    const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
     HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
     HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
     bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);

@@ -120,6 +120,12 @@ static inline void hvs_split_invalidate(hvs_index *idx, int64_t from_row) {
     if (from_row < idx->split_n) idx->split_n = from_row < 0 ? 0 : from_row;
 }
 
+#ifndef MERGE_FAN
+#define MERGE_FAN 8  // sorted lists merged by one wave of the merge kernel, one after the other (hvs_scan.hip): the chain of
+                     // merges is what a level costs, so a low fan-in and more levels win (32: 36 us, 16: 25-28 us, 8: 19-21 us
+                     // for the ~2 000 - 4 000 wave lists of a scan)
+#endif
+
 #define HVS_ROWS_SLACK 256  // zeroed bytes kept after the last row of a row matrix (see hvs_index_reserve)
 
 static inline int hvs_elem_size(int dtype) { return dtype == HVS_F32 ? 4 : 2; }

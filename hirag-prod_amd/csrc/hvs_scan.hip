@@ -17,7 +17,6 @@
 // (Eight rows in flight for single-embedding scans of 16-bit rows were measured: 57 % instead of 82 % of the HBM
 // peak on 1M x 1536 f16 -- the extra registers cost a wave per SIMD.)
 constexpr int scan_rows_in_flight(int nq, int elem_size = 4) { return nq >= 3 ? 2 : SCAN_R; }
-#define MERGE_FAN 32      // lists merged by one wave of the merge kernel
 
 struct ScanParams {
     const void *rows;
