@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--relations", type=int, default=10_000_000)
     ap.add_argument("--alpha", type=float, default=0.5)
     ap.add_argument("--repeat", type=int, default=5)
-    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the same graph (slow for big graphs)")
     a = ap.parse_args()
     import hirag_prod_amd as hvs
 
@@ -59,17 +58,6 @@ def main():
            "algorithmic_GB_per_iteration": round(bytes_per_iter / 1e9, 3),
            "GBps_incl_launch_and_sync": round(bytes_per_iter * iters / (pr_ms * 1e-3) / 1e9, 1),
            "top": [int(t) for t in top[:3]]}
-    if a.cpu:
-        from oracle import pagerank_oracle as pro
-
-        p = np.zeros(n)
-        p[seeds] = weights
-        t0 = time.perf_counter()
-        exp, exp_iters = pro.pagerank(n, src, dst, p, alpha=a.alpha)
-        out["cpu_oracle_s"] = round(time.perf_counter() - t0, 2)
-        got = g.scores()
-        out["max_abs_diff_vs_oracle"] = float(np.abs(got - exp).max())
-        out["cpu_iterations"] = exp_iters
     print(json.dumps(out))
 
 
