@@ -155,26 +155,33 @@ class _SearchCoalescer:
     async def _drain(self):
         await asyncio.sleep(0)  # the coroutines that are ready right now join the first batch
         while self._pending:
-            key = next(iter(self._pending))
-            waiting = self._pending[key]
-            batch, rest = waiting[: self.MAX_BATCH], waiting[self.MAX_BATCH :]
-            if rest:
-                self._pending[key] = rest
-            else:
-                del self._pending[key]
-            try:
-                results = await asyncio.to_thread(self._run_batch, key, [q for q, _ in batch])
-                self.launches += 1
-                self.requests += len(batch)
-                for (_, fut), res in zip(batch, results):
-                    if not fut.done():
-                        fut.set_result(res)
-            except BaseException as exc:  # every waiter of the batch sees the failure
-                for _, fut in batch:
-                    if not fut.done():
-                        fut.set_exception(exc)
-                if not isinstance(exc, Exception):
-                    raise
+            # one batch per key; the batches of one round run side by side (tables have their own HIP streams, and
+            # launches on one table queue behind that table's lock)
+            round_ = []
+            for key in list(self._pending):
+                waiting = self._pending[key]
+                batch, rest = waiting[: self.MAX_BATCH], waiting[self.MAX_BATCH :]
+                if rest:
+                    self._pending[key] = rest
+                else:
+                    del self._pending[key]
+                round_.append((key, batch))
+            await asyncio.gather(*[self._serve(key, batch) for key, batch in round_])
+
+    async def _serve(self, key: tuple, batch: list) -> None:
+        try:
+            results = await asyncio.to_thread(self._run_batch, key, [q for q, _ in batch])
+            self.launches += 1
+            self.requests += len(batch)
+            for (_, fut), res in zip(batch, results):
+                if not fut.done():
+                    fut.set_result(res)
+        except BaseException as exc:  # every waiter of the batch sees the failure; the other batches are not affected
+            for _, fut in batch:
+                if not fut.done():
+                    fut.set_exception(exc if isinstance(exc, Exception) else RuntimeError("search abandoned: the event loop is shutting down"))
+            if not isinstance(exc, Exception):
+                raise
 
 
 class HipVectorStore(BaseVDB):
