@@ -64,6 +64,18 @@ def test_10m_x_1536_f32_top10(hvs):
     _same_up_to_ties(d1, i1, dist, ids)
     d1, i1, c1 = idx.search(q, k=k, algo="mfma_split")
     _same_up_to_ties(d1, i1, dist, ids)
+    # clouds of 60 near-copies around two more queries: the filter's bound proves nothing there, those two are searched
+    # again as a batch of their own, and the answers are cloud rows all the same
+    cloud = {}
+    for j in (20, 21):
+        pos = np.array([((j - 20) * 60 + t) * 77_773 + 5 for t in range(60)], dtype=np.int64)
+        idx.update(pos, q[j][None, :] + 1e-4 * po.synth_rows(7 + j, 0, 60, d))
+        cloud[j] = set(pos.tolist())
+    dc, ic, cc = idx.search(q, k=k, algo="mfma")
+    for j in (20, 21):
+        assert cc[j] == k and set(ic[j].tolist()) <= cloud[j] and dc[j].max() < 1e-6
+    for j in (0, 1, 2, 3, 50, 127):
+        assert ic[j].tolist() == ids[j].tolist()
     # left to itself the library takes the filter route for a single query on this table too
     d1, i1, c1 = idx.search(q[9:10], k=k)
     _same_up_to_ties(d1, i1, dist[9:10], ids[9:10])
