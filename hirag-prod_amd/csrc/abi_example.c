@@ -70,8 +70,13 @@ int main(void) {
     for (int q = 0; q < 40; q++)
         for (int r = 0; r < N; r++) ref[q][r] = cos_dist(rows[r], queries[q]);
 
-    const int algos[3] = {HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32};
-    for (int a = 0; a < 3; a++) {
+    /* the fp32 table's split copy ahead of the first search (MFMA then filters on it, MFMA_SPLIT contracts all of it) */
+    int ready = 0;
+    CK(hvs_index_prepare(idx, &ready));
+    if (!ready) return 8;
+
+    const int algos[5] = {HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32, HVS_ALGO_MFMA_SPLIT, HVS_ALGO_AUTO};
+    for (int a = 0; a < 5; a++) {
         float dist[40 * K];
         int64_t ids[40 * K];
         int32_t cnt[40];
