@@ -14,7 +14,7 @@ The timed path computes in fp32 end to end (v_mfma_f32_32x32x2_f32, algo "mfma_f
 own choices for such batches are faster and are timed after the headline, on the same resident corpus
 and the same queries, under "aux": "split_f16x3" contracts a [hi | lo] fp16 split copy of the same
 fp32 rows on the 16-bit matrix pipe (three products per element, fp32 accumulation, scores within
-~1e-8 of exact arithmetic); "filter_f16_rescore_f32" (what algo "auto" / "mfma" run for k <= 32) uses
+~1e-8 of exact arithmetic); "filter_f16_rescore_f32" (what algo "auto" / "mfma" run for k <= 64) uses
 the hi slabs alone as a filter with a proven error bound, scores 4 k candidates per query again from
 the fp32 rows in fp32 and searches a query again in full when the bound does not prove its list --
 the same ids as the fp32 kernel.  Neither is the headline `value`, because their matrix products are
@@ -261,7 +261,7 @@ def main():
 
     # the routes the library takes for this batch when left to choose: fp32 rows as [hi | lo] fp16 slabs on the 16-bit
     # matrix pipe -- all three products ("mfma_split"), or one product as a filter and exact fp32 scores for 4 k
-    # candidates per query ("mfma", what AUTO picks for k <= 32)
+    # candidates per query ("mfma", what AUTO picks for k <= 64)
     if not args.no_aux:
         d_ref, i_ref, _ = out
 

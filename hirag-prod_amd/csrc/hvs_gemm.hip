@@ -1259,11 +1259,11 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
                        const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
                        int32_t *d_count, bool *used) {
     *used = false;
-    if (idx->dtype != HVS_F32 || k > MFMA_MAX_K / 4 || fold > 4 || getenv("HVS_NO_SPLIT") || getenv("HVS_NO_FILTER")) return 0;
+    if (idx->dtype != HVS_F32 || k > MFMA_MAX_K / 2 || fold > 4 || getenv("HVS_NO_SPLIT") || getenv("HVS_NO_FILTER")) return 0;
     bool have_split = false;
     HVS_TRY(hvs_split_ensure(idx, &have_split));
     if (!have_split) return 0;
-    const int kc = 4 * k < 32 ? 32 : 4 * k;  // candidates per query
+    const int kc = 4 * k < 32 ? 32 : (4 * k > MFMA_MAX_K ? MFMA_MAX_K : 4 * k);  // candidates per query: 4 k, at least 32, at most what a list holds
     const int ld16 = (idx->dim + 63) / 64 * 64;
     const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };

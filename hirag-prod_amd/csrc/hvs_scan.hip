@@ -874,7 +874,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         // at 524 288, 0.74 / 1.05 ms at 1M); from 2 GB on the filter route is taken.
         int64_t filter_min_rows = ((int64_t)500 * 1000 * 1000 + idx->ld - 1) / idx->ld;
         if (const char *e = getenv("HVS_FILTER_MIN_ROWS")) filter_min_rows = atoll(e);
-        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 32 && group_filter < 0 && !row_mask && row_end - row_begin >= filter_min_rows &&
+        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 64 && group_filter < 0 && !row_mask && row_end - row_begin >= filter_min_rows &&
             !getenv("HVS_NO_FILTER"))
             crossover = 1;
         use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);

@@ -311,7 +311,7 @@ class HvsIndex:
 
     def prepare(self) -> bool:
         """Build (or extend) the search-side copy of an fp32 table now instead of on the first batched search; True
-        when it is in place.  With it, searches with k <= 32 -- one query at a time on a large table included --
+        when it is in place.  With it, searches with k <= 64 -- one query at a time on a large table included --
         stream half the bytes and score their candidates exactly afterwards.  No-op (False) for 16-bit tables."""
         ready = ctypes.c_int(0)
         with self._lock:

@@ -40,8 +40,8 @@ enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
  * (16-bit) embeddings.  MFMA: batched contraction on the matrix cores; for fp32 rows it runs on the
  * 16-bit pipe over a split copy of the rows (two fp16 slabs per row, three products, fp32-grade
  * scores; the copy doubles the table's device memory and is built on first use) and falls back to the
- * fp32 MFMA kernel when memory does not allow the copy.  For k <= 32 the split copy is first used as a
- * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k best candidates per
+ * fp32 MFMA kernel when memory does not allow the copy.  For k <= 64 the split copy is first used as a
+ * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k (at most 128) best candidates per
  * query are scored again from the fp32 rows in fp32, and a query whose k-th exact score does not clear the
  * bound of the rows left out is searched again in full -- the exact top-k either way.  MFMA_SPLIT: the
  * three products for every score, no filter.  MFMA_F32: the fp32 MFMA kernel, no copy.
@@ -114,7 +114,7 @@ int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
 /*
  * Bring the search-side copy of an fp32 table up to date ahead of the first search (it is otherwise built by the
  * first batched search): the [hi | lo] fp16 split copy that batched searches contract and that searches with
- * k <= 32, single queries on large tables included, use as a filter before exact fp32 scoring.  The nearest
+ * k <= 64, single queries on large tables included, use as a filter before exact fp32 scoring.  The nearest
  * thing in the reference is the index DDL of PGVector._init_vdb (pgvector.py:704-726): work done once so that
  * queries are fast.  *out_ready (may be NULL) = 1 when the copy is in place, 0 when the table is 16-bit (no
  * copy needed) or device memory does not allow it (searches then stay on the fp32 kernels).

@@ -86,8 +86,8 @@ def test_split_copy_keeps_fp32_grade_scores(hvs):
     idx.update(where, new)                                      # overwritten rows invalidate it
     rows[where] = new
     dm = parity.distance_matrix(rows, q, "f32")
-    for k, algo in ((1, "mfma_split"), (10, "mfma_split"), (100, "mfma_split"), (1, "mfma"), (10, "mfma"), (32, "mfma")):
-        dist, ids, cnt = idx.search(q, k=k, algo=algo)  # "mfma" with k <= 32: hi slabs as a filter, exact fp32 rescoring
+    for k, algo in ((1, "mfma_split"), (10, "mfma_split"), (100, "mfma_split"), (1, "mfma"), (10, "mfma"), (32, "mfma"), (64, "mfma")):
+        dist, ids, cnt = idx.search(q, k=k, algo=algo)  # "mfma" with k <= 64: hi slabs as a filter, exact fp32 rescoring
         _check_all(rows, q, 1, k, dist, ids, cnt, label=f"{algo} k={k}")
         for i in range(q.shape[0]):
             c = int(cnt[i])
@@ -280,7 +280,7 @@ def test_kmeans_sums_are_reproducible_and_cover_small_k(hvs):
 
 
 def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
-    """fp32 table, k <= 32: the hi-slab filter keeps 4 k candidates per query and the answer stands only if the k-th
+    """fp32 table, k <= 64: the hi-slab filter keeps 4 k candidates per query and the answer stands only if the k-th
     exact distance clears the bound of the rows left out.  Clouds of near-duplicates around a query defeat that
     bound (hundreds of rows within 1e-4 of each other, the filter errs by up to 1e-3): such queries must come back
     exact all the same -- searched again one by one when they are few, as a whole batch when they are many."""
@@ -366,7 +366,7 @@ def test_filter_route_on_ladders_of_close_rows(hvs):
     idx = hvs.HvsIndex(d, "f32")
     idx.add(rows)
     dm = parity.distance_matrix(rows, q, "f32")
-    for k in (1, 10, 32):
+    for k in (1, 10, 32, 64):
         for algo in ("mfma", "auto"):
             qq = np.tile(q, (4, 1)) if algo == "auto" else q  # 20 embeddings: AUTO takes the matrix pipe
             dist, ids, cnt = idx.search(qq, k=k, algo=algo)
