@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +45,10 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_int64, c_int64,
          c_void_p, c_void_p, c_void_p, c_int, c_int],
+    ),
+    "hvs_search_noalloc": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
     ),
     "hvs_distances": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int]),
     "hvs_gather": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
@@ -90,6 +95,14 @@ def load_library() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `make -C {os.path.dirname(LIB_PATH)}` "
             "(or __graft_entry__.build()); there is no CPU fallback"
         )
+    # PyTorch's wheel carries its own HIP and HSA runtimes.  A process that uses both must load torch's first: libhvs
+    # then binds to the HSA runtime already in the process, whereas torch imported after libhvs has touched the GPU
+    # brings up a second HSA runtime, which finds no device ("No HIP GPUs are available").
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -816,7 +816,7 @@ static int launch_distcol_bm(int bm, bool dual, int grid, hipStream_t st, const 
 // ---------------------------------------------------------------------------------------------
 int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
-                    int32_t *d_count);  // hvs_scan.hip
+                    int32_t *d_count, void *lists = nullptr, size_t lists_bytes = 0);  // hvs_scan.hip
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count, bool positions);
 

@@ -390,6 +390,7 @@ extern "C" int hvs_index_create(hvs_index **out, int device_id, int dim, int dty
     HVS_REQUIRE(ndev > 0, "hvs_index_create: no HIP device visible (this library has no CPU path)");
     HVS_REQUIRE(device_id >= 0 && device_id < ndev, "hvs_index_create: device %d not in [0, %d)", device_id, ndev);
     HVS_HIP(hipSetDevice(device_id));
+    HVS_TRY(hvs_noalloc_setup(device_id));  // once per device, so that hvs_search_noalloc never has to
     hvs_index *idx = new hvs_index();
     idx->device = device_id;
     idx->dim = dim;

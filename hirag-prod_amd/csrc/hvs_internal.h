@@ -113,6 +113,8 @@ int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, 
 int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
                       int64_t *total);
 
+int hvs_noalloc_setup(int device);  // hvs_scan.hip: address of the scratch array of hvs_search_noalloc on `device` (current)
+
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,
                    void *dst, float *dst_inv);
 int hvs_split_ensure(hvs_index *idx, bool *ok);

@@ -9,6 +9,8 @@
 // lists to the final answer.
 #include "hvs_internal.h"
 
+#include <mutex>
+
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
 #define SCAN_R 4          // rows a wave has in flight (one or two embeddings)
@@ -729,9 +731,12 @@ static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k, int rg)
 static const size_t LDS_LIMIT = 160 * 1024;
 
 // Run the scan path for out-queries [0, nq) (already prepared on device).  Results to device buffers.
+// lists / lists_bytes: where the wave lists and the merge levels go; nullptr = the index's growable workspaces 1 and 2.
+// With a caller's buffer nothing is allocated: the out-queries per pass shrink until the lists fit, and a search whose
+// lists do not fit even one query at a time is refused.
 int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                     const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
-                    int64_t *d_ids, int32_t *d_count) {
+                    int64_t *d_ids, int32_t *d_count, void *lists, size_t lists_bytes) {
     // out-queries per pass: as many as fit 8 dot products and the LDS budget -- or 4, for 16-bit rows with
     // two to four embeddings per query: those passes run the 4x4x4 MFMA mode, which stays bandwidth-bound
     const bool m4 = idx->dtype != HVS_F32 && fold <= 4 && nq * fold >= 2;
@@ -761,8 +766,20 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const int P = grid * SCAN_WAVES;  // one list per wave
     const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
     void *bufA = nullptr, *bufB = nullptr;
-    HVS_TRY(hvs_ws_get(idx, 1, (size_t)per_pass * P * k * 8, &bufA));
-    HVS_TRY(hvs_ws_get(idx, 2, (size_t)per_pass * P2 * k * 8, &bufB));
+    if (lists) {
+        // per_pass only bounds how many of the kernel's NQ dot products a launch uses: the kernel and its LDS stay as sized
+        auto need = [&](int pp) { return (((size_t)pp * P * k * 8 + 255) & ~(size_t)255) + (size_t)pp * P2 * k * 8; };
+        while (per_pass > 1 && need(per_pass) > lists_bytes) per_pass--;
+        HVS_REQUIRE(need(per_pass) <= lists_bytes,
+                    "hvs_search_noalloc: k = %d needs %zu bytes for the %d wave lists of one query and their first merge level, the "
+                    "scratch array leaves %zu",
+                    k, need(1), P, lists_bytes);
+        bufA = lists;
+        bufB = (char *)lists + (((size_t)per_pass * P * k * 8 + 255) & ~(size_t)255);
+    } else {
+        HVS_TRY(hvs_ws_get(idx, 1, (size_t)per_pass * P * k * 8, &bufA));
+        HVS_TRY(hvs_ws_get(idx, 2, (size_t)per_pass * P2 * k * 8, &bufB));
+    }
 
     ScanParams p;
     p.rows = idx->rows;
@@ -897,7 +914,8 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
             HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
                                     split_mode));
     } else
-        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count));
+        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                nullptr, 0));
 
     if (!on_device) {
         const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
@@ -921,6 +939,62 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         }
     }
     return 0;
+}
+
+// ---- the search that allocates nothing ----------------------------------------------------------
+// Everything hvs_search takes from growable workspaces (prepared queries, inverse query norms, the wave lists of the
+// scan and the levels of their merge) lies in one array of the code object instead.  Host code never uses the array's
+// name as an address: each GPU holds its own copy, whose address hipGetSymbolAddress gives, once per device.
+#define HVS_NOALLOC_QUERY_BYTES ((size_t)1 << 20)
+static __device__ __align__(256) unsigned char hvs_noalloc_scratch[HVS_NOALLOC_SCRATCH_BYTES];
+
+#define HVS_MAX_DEVICES 64
+static void *g_noalloc_ptr[HVS_MAX_DEVICES];  // per device: address of that device's copy of the array
+static std::mutex g_noalloc_mutex;
+
+// with `device` current: look the array's address on that device up (loads the code object there on first use)
+int hvs_noalloc_setup(int device) {
+    HVS_REQUIRE(device >= 0 && device < HVS_MAX_DEVICES, "hvs_search_noalloc: device %d not in [0, %d)", device, HVS_MAX_DEVICES);
+    std::lock_guard<std::mutex> guard(g_noalloc_mutex);
+    if (g_noalloc_ptr[device]) return 0;
+    void *ptr = nullptr;
+    HVS_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(hvs_noalloc_scratch)));
+    HVS_REQUIRE(ptr != nullptr, "hvs_search_noalloc: hipGetSymbolAddress returned no address on device %d", device);
+    g_noalloc_ptr[device] = ptr;
+    return 0;
+}
+
+extern "C" int hvs_search_noalloc(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter,
+                                  const uint32_t *row_mask, double max_distance, int64_t row_begin, int64_t row_end,
+                                  float *out_dist, int64_t *out_ids, int32_t *out_count) {
+    HVS_REQUIRE(idx != nullptr, "hvs_search_noalloc: idx is NULL");
+    HVS_REQUIRE(nq >= 0, "hvs_search_noalloc: negative query count");
+    if (nq == 0) return 0;
+    HVS_REQUIRE(queries && out_dist && out_ids && out_count, "hvs_search_noalloc: NULL argument");
+    HVS_REQUIRE(fold >= 1 && fold <= HVS_MAX_FOLD, "hvs_search_noalloc: fold %d not in [1, %d]", fold, HVS_MAX_FOLD);
+    HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_search_noalloc: k %d not in [1, %d]", k, HVS_MAX_K);
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    if (row_begin > row_end) row_begin = row_end;
+    const int nq_total = nq * fold;
+    const size_t q_bytes = (size_t)nq_total * idx->ld * 4;
+    const size_t inv_off = (q_bytes + 255) & ~(size_t)255;
+    const size_t q_end = (inv_off + (size_t)nq_total * 4 + 255) & ~(size_t)255;
+    HVS_REQUIRE(q_end <= HVS_NOALLOC_QUERY_BYTES,
+                "hvs_search_noalloc: %d query embeddings of %d columns take %zu bytes, the scratch array keeps %zu for them", nq_total,
+                idx->dim, q_end, HVS_NOALLOC_QUERY_BYTES);
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_TRY(hvs_noalloc_setup(idx->device));  // a table look-up after hvs_index_create has run on this device
+    char *scratch = (char *)g_noalloc_ptr[idx->device];
+
+    float *d_q = (float *)scratch, *d_qinv = (float *)(scratch + inv_off);
+    prep_queries_kernel<<<(nq_total + 3) / 4, 256, 0, idx->stream>>>(queries, d_q, d_qinv, nq_total, idx->dim, idx->ld, idx->dtype);
+    HVS_HIP(hipGetLastError());
+    // every wave of the scan writes all k keys of its list and every merge level writes all of its outputs, so nothing
+    // in the array has to start at zero: what the previous call left is overwritten before it is read
+    return hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, row_mask, hvs_ceil_to_float(max_distance), row_begin, row_end,
+                           out_dist, out_ids, out_count, scratch + HVS_NOALLOC_QUERY_BYTES,
+                           HVS_NOALLOC_SCRATCH_BYTES - HVS_NOALLOC_QUERY_BYTES);
 }
 
 int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int m, int64_t row_begin, int64_t row_end, float *d_out,

@@ -168,6 +168,25 @@ int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k,
                int on_device, int algo);
 
 /*
+ * hvs_search for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same statement and the same answers as hvs_search with
+ * on_device = 1 and HVS_ALGO_SCAN (the streaming scan; every pointer is memory of the index's GPU; returns after
+ * the work has been submitted to the index's stream), but the prepared queries, the wave lists and the merge levels
+ * live in one HVS_NOALLOC_SCRATCH_BYTES array inside the library's code object -- held by every GPU the library runs
+ * on until the process ends -- and the call makes no hipMalloc / hipFree / allocating library call
+ * (hvs_index_create looks the array's address up once per device).  Limits, refused with a message:
+ * nq * fold * (4 * padded dim + 4) <= 1 MiB (170 embeddings of 1536 columns), and the lists of one query must fit
+ * the rest: k * 8 bytes * 1.125 * (4 waves * resident blocks, at most 4096 lists) <= 7 MiB, i.e. k <= 199 on a
+ * full grid, any k <= HVS_MAX_K on tables small enough for fewer blocks.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU -- on different indexes or streams too -- race; serialise them.
+ */
+#define HVS_NOALLOC_SCRATCH_BYTES (8u << 20)
+int hvs_search_noalloc(hvs_index *idx, const float *queries, int nq, int fold, int k,
+                       int32_t group_filter, const uint32_t *row_mask, double max_distance,
+                       int64_t row_begin, int64_t row_end,
+                       float *out_dist, int64_t *out_ids, int32_t *out_count);
+
+/*
  * Full distance column.  Replaces the projected LEAST(Item.vector <=> e_i)
  * column of cross-language search
  * (src/hirag_prod/cross_language_search/search_service.py:100-113):
