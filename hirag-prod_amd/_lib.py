@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libhvs.so")
 
 HVS_F32, HVS_F16, HVS_BF16 = 0, 1, 2
 HVS_ALGO_AUTO, HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32, HVS_ALGO_MFMA_SPLIT = 0, 1, 2, 3, 4
-HVS_PROF_SCAN, HVS_PROF_MFMA_SEARCH, HVS_PROF_KMEANS_ASSIGN, HVS_PROF_KMEANS_UPDATE, HVS_PROF_MERGE = range(5)
+HVS_PROF_SCAN, HVS_PROF_MFMA_SEARCH, HVS_PROF_KMEANS_ASSIGN, HVS_PROF_KMEANS_UPDATE, HVS_PROF_MERGE, HVS_PROF_REDO = range(6)
 HVS_MAX_K = 1024
 HVS_MAX_FOLD = 8
 HVS_MAX_DIST_FOLD = 128
@@ -41,6 +41,7 @@ SIGNATURES = {
     "hvs_index_update": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]),
     "hvs_index_set_deleted": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     "hvs_index_fill_synthetic": (c_int, [c_void_p, c_int64, c_uint64, c_int64, c_int32]),
+    "hvs_index_fill_clustered": (c_int, [c_void_p, c_int64, c_uint64, c_int64, c_int32, c_int64]),
     "hvs_search": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_int64, c_int64,

@@ -1263,6 +1263,11 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     bool have_split = false;
     HVS_TRY(hvs_split_ensure(idx, &have_split));
     if (!have_split) return 0;
+    const bool adapt = !getenv("HVS_NO_ADAPT");
+    if (adapt && idx->filter_skip > 0) {  // recent filter passes on this table proved nothing: do not pay for another yet
+        idx->filter_skip--;
+        return 0;
+    }
     const int kc = 4 * k < 32 ? 32 : (4 * k > MFMA_MAX_K ? MFMA_MAX_K : 4 * k);  // candidates per query: 4 k, at least 32, at most what a list holds
     const int ld16 = (idx->dim + 63) / 64 * 64;
     const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
@@ -1292,6 +1297,14 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     int n_redo = 0;
     for (int i = 0; i < nq; i++) n_redo += redo[i] != 0;
     *used = true;
+    idx->prof_launches[HVS_PROF_REDO] += n_redo;
+    if (adapt) {
+        if (2 * n_redo > nq) {
+            idx->filter_backoff = idx->filter_backoff == 0 ? 4 : (idx->filter_backoff >= 32 ? 64 : 2 * idx->filter_backoff);
+            idx->filter_skip = idx->filter_backoff;
+        } else
+            idx->filter_backoff = 0;
+    }
     if (n_redo == 0) return 0;
     if (n_redo == 1 || (!sub_ok && n_redo <= 8)) {  // one exact scan per flagged query
         for (int i = 0; i < nq; i++)

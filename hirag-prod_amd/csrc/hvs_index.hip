@@ -102,6 +102,48 @@ __global__ void fill_synth_kernel(T *__restrict__ rows, int64_t n, int dim, int 
     }
 }
 
+// Clustered corpus: row r = centre[c(r)] + sigma[c(r)] * noise[r], every term a value of the generator above.
+//   c(r)      = splitmix64(r ^ splitmix64(seed ^ 0xC1)) mod n_clusters      (members scattered over the table)
+//   level(c)  = splitmix64(c ^ splitmix64(seed ^ 0xC2)) & 7, sigma = sqrt of {1, 1.4, 2, 2.8, 4, 5.6, 8, 10}e-3 as float
+//   centre[c] = row c of the plain generator under seed + 1;  noise[r] = row r under seed
+// Two members of one cluster lie at cosine distance ~ sigma^2 of each other (1e-3 .. 1e-2).  The product and the sum
+// are rounded separately (no fused multiply-add), so that float32 arithmetic on any host gives the same bits.
+__device__ __forceinline__ float hvs_synth_value(uint64_t ctr, uint64_t seed_mix) {
+    const uint64_t h = hvs_splitmix64(ctr ^ seed_mix);
+    const int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) + (int)((h >> 48) & 0xFFFF) - 131070;
+    return (float)s * (1.0f / 37837.0f);
+}
+
+struct hvs_cluster_params {
+    uint64_t mix_noise, mix_centre, mix_assign, mix_level;
+    uint64_t n_clusters;
+    float sigma[8];
+};
+
+template <typename T>
+__global__ void fill_clustered_kernel(T *__restrict__ rows, int64_t n, int dim, int ld, int64_t first_pos, int64_t first_global,
+                                      hvs_cluster_params cp) {
+    const int64_t total = n * (int64_t)ld;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld;
+        const int c = (int)(i - r * ld);
+        float v = 0.0f;
+        if (c < dim) {
+            const uint64_t g = (uint64_t)(first_global + r);
+            const uint64_t cl = hvs_splitmix64(g ^ cp.mix_assign) % cp.n_clusters;
+            const float sigma = cp.sigma[hvs_splitmix64(cl ^ cp.mix_level) & 7];
+            const float centre = hvs_synth_value(cl * (uint64_t)dim + (uint64_t)c, cp.mix_centre);
+            const float noise = hvs_synth_value(g * (uint64_t)dim + (uint64_t)c, cp.mix_noise);
+            {
+#pragma clang fp contract(off)  // two roundings, as plain float32 arithmetic on a host does
+                const float prod = sigma * noise;
+                v = centre + prod;
+            }
+        }
+        rows[(first_pos + r) * ld + c] = hvs_cvt<float, T>(v);
+    }
+}
+
 __global__ void fill_meta_kernel(int64_t *ids, int32_t *groups, int64_t n, int64_t first_pos, int64_t first_id,
                                  int32_t n_groups, const int64_t *src_ids, const int32_t *src_groups) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -771,6 +813,51 @@ extern "C" int hvs_index_fill_synthetic(hvs_index *idx, int64_t n, uint64_t seed
         inv_norm_kernel<__half><<<grid_for(n * 64), 256, 0, s>>>((const __half *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
     } else {
         fill_synth_kernel<uint16_t><<<g, 256, 0, s>>>((uint16_t *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, seed_mix);
+        inv_norm_kernel<uint16_t><<<grid_for(n * 64), 256, 0, s>>>((const uint16_t *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    }
+    HVS_HIP(hipGetLastError());
+    fill_meta_kernel<<<grid_for(n), 256, 0, s>>>(idx->ids, idx->groups, n, first, first_global_row, n_groups, nullptr, nullptr);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipStreamSynchronize(s));
+    idx->n += n;
+    return 0;
+}
+
+static uint64_t host_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+extern "C" int hvs_index_fill_clustered(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row, int32_t n_groups,
+                                        int64_t n_clusters) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_fill_clustered: idx is NULL");
+    HVS_REQUIRE(n >= 0 && first_global_row >= 0, "hvs_index_fill_clustered: negative argument");
+    HVS_REQUIRE(n_clusters >= 1, "hvs_index_fill_clustered: n_clusters %lld < 1", (long long)n_clusters);
+    if (n == 0) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    if (idx->n + n > idx->cap) HVS_TRY(hvs_index_reserve(idx, idx->n + n));
+    const int64_t first = idx->n;
+    hvs_cluster_params cp;
+    cp.mix_noise = host_splitmix64(seed);
+    cp.mix_centre = host_splitmix64(seed + 1);
+    cp.mix_assign = host_splitmix64(seed ^ 0xC1);
+    cp.mix_level = host_splitmix64(seed ^ 0xC2);
+    cp.n_clusters = (uint64_t)n_clusters;
+    static const double spread[8] = {1.0e-3, 1.4e-3, 2.0e-3, 2.8e-3, 4.0e-3, 5.6e-3, 8.0e-3, 1.0e-2};
+    for (int i = 0; i < 8; i++) cp.sigma[i] = (float)std::sqrt(spread[i]);
+    const int g = grid_for(n * (int64_t)idx->ld, 256, 256 * 16);
+    hipStream_t s = idx->stream;
+    hvs_split_invalidate(idx, first);
+    if (idx->dtype == HVS_F32) {
+        fill_clustered_kernel<float><<<g, 256, 0, s>>>((float *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, cp);
+        inv_norm_kernel<float><<<grid_for(n * 64), 256, 0, s>>>((const float *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    } else if (idx->dtype == HVS_F16) {
+        fill_clustered_kernel<__half><<<g, 256, 0, s>>>((__half *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, cp);
+        inv_norm_kernel<__half><<<grid_for(n * 64), 256, 0, s>>>((const __half *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
+    } else {
+        fill_clustered_kernel<uint16_t><<<g, 256, 0, s>>>((uint16_t *)idx->rows, n, idx->dim, idx->ld, first, first_global_row, cp);
         inv_norm_kernel<uint16_t><<<grid_for(n * 64), 256, 0, s>>>((const uint16_t *)idx->rows, idx->inv_norm, n, idx->ld, first, nullptr);
     }
     HVS_HIP(hipGetLastError());

@@ -72,6 +72,10 @@ struct hvs_index {
     float *split_inv = nullptr;
     int64_t split_cap = 0, split_n = 0;
     bool split_failed = false;  // device memory did not allow the copy
+    // the filter route learns from its own outcome: after a call in which more than half of the candidate lists proved
+    // nothing (a table of tight clusters), the next filter_skip calls go straight to the route that scores every row in
+    // full; the run of skipped calls doubles with every failure in a row (4, 8, ... 64) and ends with the first success
+    int filter_skip = 0, filter_backoff = 0;
 
     hvs_workspace ws[8];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
                           // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,

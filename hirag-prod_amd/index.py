@@ -149,6 +149,11 @@ class HvsIndex:
         with self._lock:
             check(self._lib.hvs_index_fill_synthetic(self._h, int(n), int(seed), int(first_global_row), int(n_groups)))
 
+    def fill_clustered(self, n: int, seed: int = 1234, first_global_row: int = 0, n_groups: int = 0, n_clusters: int = 10_000) -> None:
+        """Append ``n`` rows of the clustered synthetic corpus (``hvs_index_fill_clustered``)."""
+        with self._lock:
+            check(self._lib.hvs_index_fill_clustered(self._h, int(n), int(seed), int(first_global_row), int(n_groups), int(n_clusters)))
+
     # -- search ----------------------------------------------------------------------------------
     def search(self, queries, k: int = 10, fold: int = 1, group_filter: int = -1, row_mask=None,
                max_distance: float = math.inf, row_begin: int = 0, row_end: int = -1, algo: str = "auto"):

@@ -51,7 +51,9 @@ enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F3
 
 /* counters readable through hvs_profile_get */
 enum { HVS_PROF_SCAN = 0, HVS_PROF_MFMA_SEARCH = 1, HVS_PROF_KMEANS_ASSIGN = 2, HVS_PROF_KMEANS_UPDATE = 3,
-       HVS_PROF_MERGE = 4, HVS_PROF_COUNT = 5 };
+       HVS_PROF_MERGE = 4,
+       HVS_PROF_REDO = 5, /* launches = queries whose filtered candidate list proved nothing and that were searched again in full (no time) */
+       HVS_PROF_COUNT = 6 };
 
 #define HVS_MAX_K 1024       /* largest top-k a search accepts */
 #define HVS_MAX_FOLD 8       /* largest number of query embeddings folded by LEAST */
@@ -143,6 +145,18 @@ int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64
  */
 int hvs_index_fill_synthetic(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row,
                              int32_t n_groups);
+
+/*
+ * The same for a clustered corpus, the shape text-embedding tables have: n_clusters centres (rows of the generator
+ * above under seed + 1), global row r belongs to cluster splitmix64(r ^ splitmix64(seed ^ 0xC1)) mod n_clusters and is
+ * centre + sigma * noise with noise = row r of the generator above under seed, the product and the sum each rounded to
+ * float (no fused multiply-add); sigma^2 = one of {1, 1.4, 2, 2.8, 4, 5.6, 8, 10}e-3 chosen per cluster c by
+ * splitmix64(c ^ splitmix64(seed ^ 0xC2)) & 7, so that two members of a cluster lie at cosine distance 1e-3 .. 1e-2 of
+ * each other.  Queries of the same distribution: rows at global numbers past the corpus.  ids and group codes as above.
+ * (Benchmark and parity-at-scale support; no reference counterpart.)
+ */
+int hvs_index_fill_clustered(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row,
+                             int32_t n_groups, int64_t n_clusters);
 
 /*
  * Exact cosine top-k.  Replaces the statement PGVector.query builds and

@@ -199,3 +199,30 @@ def synth_rows(seed: int, row_begin: int, n: int, dim: int) -> np.ndarray:
         - 131070
     )
     return s.astype(np.float32) * SYNTH_SCALE
+
+
+CLUSTER_SPREAD = (1.0e-3, 1.4e-3, 2.0e-3, 2.8e-3, 4.0e-3, 5.6e-3, 8.0e-3, 1.0e-2)
+
+
+def synth_cluster_of(seed: int, row_begin: int, n: int, n_clusters: int) -> np.ndarray:
+    """Cluster number of global rows ``[row_begin, row_begin + n)`` of the clustered synthetic corpus."""
+    rows = np.arange(row_begin, row_begin + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        mix = _splitmix64(np.array([np.uint64(seed) ^ np.uint64(0xC1)], dtype=np.uint64))
+        return (_splitmix64(rows ^ mix) % np.uint64(n_clusters)).astype(np.int64)
+
+
+def synth_clustered_rows(seed: int, row_begin: int, n: int, dim: int, n_clusters: int) -> np.ndarray:
+    """Host twin of the device's clustered generator (``hvs_index_fill_clustered``), float32 ``[n, dim]``, bit for bit:
+    centre of the row's cluster (row c of ``synth_rows(seed + 1, ...)``) + sigma(c) * ``synth_rows(seed, ...)``, the
+    product and the sum each rounded to float32."""
+    cl = synth_cluster_of(seed, row_begin, n, n_clusters)
+    with np.errstate(over="ignore"):
+        mix = _splitmix64(np.array([np.uint64(seed) ^ np.uint64(0xC2)], dtype=np.uint64))
+        level = (_splitmix64(cl.astype(np.uint64) ^ mix) & np.uint64(7)).astype(np.int64)
+    sigma = np.sqrt(np.array(CLUSTER_SPREAD, dtype=np.float64)).astype(np.float32)[level]
+    uniq, inv = np.unique(cl, return_inverse=True)
+    centres = np.concatenate([synth_rows(seed + 1, int(c), 1, dim) for c in uniq]) if len(uniq) else np.zeros((0, dim), np.float32)
+    noise = synth_rows(seed, row_begin, n, dim)
+    prod = (sigma[:, None] * noise).astype(np.float32)
+    return (centres[inv] + prod).astype(np.float32)

@@ -326,11 +326,26 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
         parity.check_topk(dist1[i], ids1[i], cnt1[i], dm[i], 10, label=f"one q={i}")
     # every query inside a cloud: the whole batch is searched again with all three products
     qc = (centre[rng.integers(0, 3, 64)] + 1e-3 * rng.standard_normal((64, d))).astype(np.float32)
-    (dist, ids, cnt), scans, full = run(qc, 10)
+    os.environ["HVS_NO_ADAPT"] = "1"  # pin the route: a failed filter pass otherwise keeps the next calls off it
+    try:
+        (dist, ids, cnt), scans, full = run(qc, 10)
+    finally:
+        del os.environ["HVS_NO_ADAPT"]
     assert scans == 0 and full == 2
     dmc = parity.distance_matrix(rows, qc, "f32")
     for i in range(64):
         parity.check_topk(dist[i], ids[i], cnt[i], dmc[i], 10, label=f"many q={i}")
+    # left to itself the table remembers: the call after a batch whose lists proved nothing skips the filter pass (one
+    # kernel, all three products), four calls later the filter is tried again; the answers do not change
+    (dist2, ids2, cnt2), scans, full = run(qc, 10)
+    assert scans == 0 and full == 1
+    assert np.array_equal(ids2, ids) and np.array_equal(cnt2, cnt)
+    for _ in range(3):
+        idx.search(qc, k=10, algo="mfma")
+    (dist3, ids3, cnt3), scans, full = run(q, 10)  # run() searches twice: the filter is back, and proves 198 of 200 lists
+    assert scans == 0 and full == 2
+    for i in range(200):
+        parity.check_topk(dist3[i], ids3[i], cnt3[i], dm[i], 10, label=f"after the back-off q={i}")
     # nothing to prove when the candidate list was not cut: fewer live rows than candidates
     (dist, ids, cnt), scans, full = run(q[:20], 10, row_begin=1000, row_end=1030)
     assert scans == 0 and full == 1
