@@ -49,24 +49,23 @@ F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(n_threads: int):
-    """pgvector-style scan in C on the host: queries/s scaled to the 10M-row corpus."""
+def cpu_baseline(n_threads: int, rows: np.ndarray):
+    """pgvector-style scan in C on the host over `rows` (a >= 1M-row slice of the benchmark corpus, exported from
+    the GPU): queries/s scaled linearly to the 10M-row corpus."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pgv_scan
 
     pgv_scan.load()
-    sample_rows = 65536
-    rng = np.random.default_rng(SEED_CORPUS)
-    rows = rng.standard_normal((sample_rows, DIM), dtype=np.float32)
+    sample_rows = rows.shape[0]
     rng = np.random.default_rng(SEED_QUERY)
     # calibrate: one query on one thread
     q1 = rng.standard_normal((1, DIM), dtype=np.float32)
     t0 = time.perf_counter()
     pgv_scan.scan_topk(rows, q1, TOPK)
     t1 = time.perf_counter() - t0
-    # aim at ~15 s of CPU work in total
-    n_queries = int(max(n_threads, min(4096, 15.0 / max(t1, 1e-4))))
+    # aim at ~20 s of CPU work in total, at least two queries per thread
+    n_queries = int(max(2 * n_threads, min(4096, 20.0 / max(t1, 1e-4))))
     n_queries = (n_queries + n_threads - 1) // n_threads * n_threads
     queries = rng.standard_normal((n_queries, DIM), dtype=np.float32)
 
@@ -81,7 +80,7 @@ def cpu_baseline(n_threads: int):
     qps_full = qps_sample * sample_rows / N_ROWS
     # second variant: the numpy statement of the same search (hirag.py:1305-1327: normalised rows, C @ q, argsort),
     # batched -- one sgemm of the sample against a block of queries on the BLAS threads, then argpartition + sort
-    nb = 1024
+    nb = 128
     qb = rng.standard_normal((nb, DIM), dtype=np.float32)
     t0 = time.perf_counter()
     inv = 1.0 / np.sqrt(np.einsum("ij,ij->i", rows, rows))
@@ -102,9 +101,195 @@ def cpu_baseline(n_threads: int):
         "unit": "queries/s",
         "cores": n_threads,
         "kind": "port",
-        "sample": f"{n_queries} queries x {sample_rows} rows x {DIM} f32 in {wall:.2f} s wall on {n_threads} threads "
-                  f"(oracle/pgv_scan.c, pgvector-style scan + top-{TOPK} heap), scaled linearly to {N_ROWS} rows",
+        "sample": f"{n_queries} queries x {sample_rows} rows x {DIM} f32 (the first rows of the benchmark corpus) in {wall:.2f} s "
+                  f"wall on {n_threads} threads (oracle/pgv_scan.c, pgvector-style scan + top-{TOPK} heap), scaled linearly to "
+                  f"{N_ROWS} rows",
     }
+
+
+def stats_ms(samples):
+    """median / p95 / mean of per-iteration times in ms"""
+    a = np.sort(np.asarray(samples, dtype=np.float64))
+    return {"median_ms": float(np.median(a)), "p95_ms": float(a[min(len(a) - 1, int(np.ceil(0.95 * len(a))) - 1)]),
+            "mean_ms": float(a.mean()), "iterations": int(len(a))}
+
+
+def timed_calls(torch, fn, iters, warm=3):
+    """per-call wall time (ms) of fn(), each call bracketed by a device synchronisation"""
+    for _ in range(warm):
+        fn()
+    out = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) * 1e3)
+    return out
+
+
+def kernel_ms(idx, which, fn, torch, iters, warm=2):
+    """per-launch device time of kernel classes (HIP events on the index's stream), one sample per call of fn();
+    `which`: one counter -> list of ms, or a tuple of counters -> one list per counter"""
+    many = isinstance(which, tuple)
+    counters = which if many else (which,)
+    for _ in range(warm):
+        fn()
+    idx.profile(True)
+    out = [[] for _ in counters]
+    for _ in range(iters):
+        idx.profile_reset()
+        fn()
+        for o, w in zip(out, counters):
+            ms, n = idx.profile_get(w)
+            o.append(ms / max(n, 1))
+    idx.profile(False)
+    return out if many else out[0]
+
+
+def leg_cfg2(hvs, _lib, torch, dev):
+    """BASELINE config 2: 1M x 1536 fp32, one query per call, top-10 (GEMV, HBM-bound)."""
+    n = 1_000_000
+    idx = hvs.HvsIndex(DIM, "f32", device=dev.index)
+    idx.fill_synthetic(n, seed=SEED_CORPUS)
+    gen = torch.Generator(device=dev).manual_seed(SEED_QUERY)
+    q = torch.randn((32, DIM), device=dev, dtype=torch.float32, generator=gen)
+    qh = q.cpu().numpy()
+    state = {"i": 0}
+
+    def one(algo, host):
+        def f():
+            i = state["i"] = (state["i"] + 1) % 32
+            if host:
+                idx.search(qh[i : i + 1], k=TOPK, algo=algo)
+            else:
+                idx.search(q[i : i + 1], k=TOPK, algo=algo)
+        return f
+
+    bytes_q = n * DIM * 4
+    kern = stats_ms(kernel_ms(idx, _lib.HVS_PROF_SCAN, one("scan", False), torch, 30))
+    e2e = stats_ms(timed_calls(torch, one("scan", True), 30))
+    out = {
+        "workload": f"{n} x {DIM} fp32, 1 query per call, top-{TOPK}, no filter",
+        "scan_kernel": kern,
+        "scan_kernel_GBps": bytes_q / (kern["median_ms"] * 1e-3) / 1e9,
+        "scan_kernel_frac_of_hbm_peak": bytes_q / (kern["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_query": bytes_q,
+        "end_to_end_host_buffers": e2e,
+        "end_to_end_qps": 1e3 / e2e["median_ms"],
+    }
+    # the library's own choice once the table's split copy exists: hi slabs as a filter, exact fp32 rescoring
+    idx.prepare()
+    os.environ["HVS_FILTER_MIN_ROWS"] = "1"
+    try:
+        e2e_auto = stats_ms(timed_calls(torch, one("auto", True), 30))
+    finally:
+        del os.environ["HVS_FILTER_MIN_ROWS"]
+    out["end_to_end_filter_route"] = e2e_auto
+    out["end_to_end_filter_route_qps"] = 1e3 / e2e_auto["median_ms"]
+    idx.close()
+    return out
+
+
+def leg_cfg4(idx, hvs, _lib, torch, dev, rows):
+    """BASELINE config 4: one Lloyd iteration, K = 4096 centroids (the first rows) over the resident 10M corpus."""
+    K = 4096
+    c = torch.from_numpy(idx.gather(np.arange(K))).to(dev)
+    out = {"workload": f"{rows} x {DIM} fp32 rows, K = {K}, one Lloyd iteration (assign + partial sums + centroid division)"}
+    flops = 2.0 * K * rows * DIM
+    for label, env in (("split_f16x3", None), ("fp32_mfma", "HVS_NO_SPLIT")):
+        if env:
+            os.environ[env] = "1"
+        try:
+            def it():
+                assign, sums, counts = idx.kmeans_assign(c)
+                torch.where((counts > 0).unsqueeze(1), sums / counts.clamp(min=1).unsqueeze(1).float(), c)
+            iters = 5 if env is None else 3
+            wall = stats_ms(timed_calls(torch, it, iters, warm=1))
+            a, u = (stats_ms(v) for v in kernel_ms(idx, (_lib.HVS_PROF_KMEANS_ASSIGN, _lib.HVS_PROF_KMEANS_UPDATE), it, torch, iters, warm=0))
+        finally:
+            if env:
+                del os.environ[env]
+        peak = FP32_MFMA_PEAK_TFLOPS if env else F16_MFMA_PEAK_TFLOPS
+        executed = flops * (1.0 if env else 3.0)
+        out[label] = {
+            "iteration": wall,
+            "assign_kernel": a,
+            "assign_algorithmic_TFLOPs": flops / (a["median_ms"] * 1e-3) / 1e12,
+            "assign_executed_TFLOPs": executed / (a["median_ms"] * 1e-3) / 1e12,
+            "assign_frac_of_peak_executed": executed / (a["median_ms"] * 1e-3) / 1e12 / peak,
+            "peak_TFLOPs": peak,
+            "update_pass": u,
+            "update_GBps": rows * DIM * 4 / (u["median_ms"] * 1e-3) / 1e9,
+        }
+    return out
+
+
+def leg_cfg5(hvs, _lib, torch, dev):
+    """BASELINE config 5, one GPU's shard: 12.5M x 768 bf16 (1/8 of 100M), top-100, 64 workspaces."""
+    n, d, k = 12_500_000, 768, 100
+    idx = hvs.HvsIndex(d, "bf16", device=dev.index)
+    idx.fill_synthetic(n, seed=SEED_CORPUS, first_global_row=25_000_000, n_groups=64)
+    gen = torch.Generator(device=dev).manual_seed(SEED_QUERY)
+    q = torch.randn((256, d), device=dev, dtype=torch.float32, generator=gen)
+    out = {"workload": f"{n} x {d} bf16 shard (rank 2 of 8 of a 100M-row table), top-{k}, group code = row mod 64"}
+    for label, kw, nq, algo, which in (
+        ("single_query", {}, 1, "scan", _lib.HVS_PROF_SCAN),
+        ("single_query_workspace_filter", {"group_filter": 3}, 1, "scan", _lib.HVS_PROF_SCAN),
+        ("batch_256", {}, 256, "mfma", _lib.HVS_PROF_MFMA_SEARCH),
+        ("batch_256_workspace_filter", {"group_filter": 3}, 256, "mfma", _lib.HVS_PROF_MFMA_SEARCH),
+    ):
+        qq = q[:nq].contiguous()
+
+        def f():
+            idx.search(qq, k=k, algo=algo, **kw)
+
+        wall = stats_ms(timed_calls(torch, f, 20))
+        kern = stats_ms(kernel_ms(idx, which, f, torch, 20))
+        live = n // 64 if kw else n
+        hbm_floor = live * d * 2 / (HBM_PEAK_GBS * 1e9) * 1e3
+        mfma_floor = 2.0 * nq * live * d / (F16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        out[label] = {
+            "call": wall, "qps": nq * 1e3 / wall["median_ms"], "kernel": kern,
+            "live_rows": live, "hbm_floor_ms": hbm_floor, "mfma_floor_ms": mfma_floor,
+            "kernel_over_floor": kern["median_ms"] / max(hbm_floor, mfma_floor),
+            "kernel_GBps_of_live_bytes": live * d * 2 / (kern["median_ms"] * 1e-3) / 1e9,
+            "kernel_TFLOPs": 2.0 * nq * live * d / (kern["median_ms"] * 1e-3) / 1e12,
+        }
+    idx.close()
+    return out
+
+
+def leg_clustered(hvs, _lib, torch, dev, batch):
+    """The library's default route on a corpus of tight clusters (where the filter pass's bound proves little)."""
+    n, n_clusters = 2_000_000, 10_000
+    idx = hvs.HvsIndex(DIM, "f32", device=dev.index)
+    idx.fill_clustered(n, seed=SEED_CORPUS, n_clusters=n_clusters)
+    qi = hvs.HvsIndex(DIM, "f32", device=dev.index)
+    qi.fill_clustered(batch, seed=SEED_CORPUS, first_global_row=1_000_000_000, n_clusters=n_clusters)
+    q = torch.from_numpy(qi.export()[0]).to(dev)
+    qi.close()
+    idx.prepare()
+    out = {"workload": f"{n} x {DIM} fp32 rows in {n_clusters} clusters (cosine spread 1e-3..1e-2 inside a cluster), "
+                       f"{batch} queries of the same distribution per call, top-{TOPK}"}
+    os.environ["HVS_NO_ADAPT"] = "1"
+    try:
+        idx.profile_reset()
+        d_f, i_f, _ = idx.search(q, k=TOPK, algo="mfma")
+        redone = idx.profile_get(_lib.HVS_PROF_REDO)[1]
+        fixed = stats_ms(timed_calls(torch, lambda: idx.search(q, k=TOPK, algo="mfma"), 5, warm=1))
+    finally:
+        del os.environ["HVS_NO_ADAPT"]
+    d_s, i_s, _ = idx.search(q, k=TOPK, algo="mfma_split")
+    auto = stats_ms(timed_calls(torch, lambda: idx.search(q, k=TOPK), 20, warm=2))
+    out.update({
+        "queries_searched_again_in_full": int(redone), "queries": batch,
+        "filter_route_every_call": fixed, "filter_route_every_call_qps": batch * 1e3 / fixed["median_ms"],
+        "default_route_with_back_off": auto, "default_route_qps": batch * 1e3 / auto["median_ms"],
+        "ids_equal_to_three_product_route": float((i_f == i_s).float().mean().item()),
+    })
+    idx.close()
+    return out
 
 
 def measured_traffic(rows_per_gpu, batch):
@@ -184,6 +369,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # median / p95 of single steps, each synchronised on its own (outside the timed region above)
+    step_stats = stats_ms(timed_calls(torch, step, min(max(args.steps, 5), 10), warm=0)) if world == 1 else None
+
     # sanity on the last result: sorted, full, ids in range (not a parity check; tests do that)
     d_last, i_last, c_last = out
     assert int(c_last.min().item()) == TOPK
@@ -204,6 +392,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "step_ms_stats": step_stats,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -354,12 +543,20 @@ def main():
     if rank == 0:
         # timed at N = 1 only, on this host's cores (at most 16: the GPU box's CPU share per GPU)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1))
+            sample = min(hi - lo, 1_048_576)
+            result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1), idx.export(0, sample)[0])
         else:
             result["cpu_baseline"] = None
+    # the other BASELINE configurations, each on a freshly filled table of its own (one GPU only: they are per-GPU figures)
+    if world == 1 and not args.no_aux:
+        result["aux"]["cfg4_kmeans"] = leg_cfg4(idx, hvs, _lib, torch, dev, hi - lo)
     if world > 1:
         dist.barrier()
     idx.close()
+    if world == 1 and not args.no_aux:
+        result["aux"]["cfg2"] = leg_cfg2(hvs, _lib, torch, dev)
+        result["aux"]["cfg5_shard"] = leg_cfg5(hvs, _lib, torch, dev)
+        result["aux"]["clustered"] = leg_clustered(hvs, _lib, torch, dev, args.batch)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

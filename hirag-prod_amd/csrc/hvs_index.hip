@@ -703,8 +703,11 @@ extern "C" int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *
     hipStream_t s = idx->stream;
     if (rows) {
         const size_t row_bytes = (size_t)idx->dim * idx->elem_size, pitch = (size_t)idx->ld * idx->elem_size;
-        HVS_HIP(hipMemcpy2DAsync(rows, row_bytes, (const char *)idx->rows + (size_t)first * pitch, pitch, row_bytes, (size_t)n,
-                                 hipMemcpyDeviceToHost, s));
+        if (pitch == row_bytes)  // no pad columns: one linear copy (a 2-D copy was seen to deliver nothing under rocprofv3's tracer)
+            HVS_HIP(hipMemcpyAsync(rows, (const char *)idx->rows + (size_t)first * pitch, row_bytes * (size_t)n, hipMemcpyDeviceToHost, s));
+        else
+            HVS_HIP(hipMemcpy2DAsync(rows, row_bytes, (const char *)idx->rows + (size_t)first * pitch, pitch, row_bytes, (size_t)n,
+                                     hipMemcpyDeviceToHost, s));
     }
     if (ids) HVS_HIP(hipMemcpyAsync(ids, idx->ids + first, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     if (group_codes) HVS_HIP(hipMemcpyAsync(group_codes, idx->groups + first, (size_t)n * 4, hipMemcpyDeviceToHost, s));
