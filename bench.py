@@ -326,6 +326,12 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        if world > 1:  # a launcher on a box without a GPU: meet the other ranks, then say what is missing
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit("bench.py: no HIP device visible (this benchmark has no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -333,7 +339,25 @@ def main():
 
     import hirag_prod_amd as hvs
     from hirag_prod_amd import _lib
-    from hirag_prod_amd.sharded import ShardedSearch, shard_range
+    from hirag_prod_amd.sharded import HvsComm, ShardedSearch, shard_range
+
+    # the exchange between the shards runs inside libhvs: RCCL on the index's stream.  torch.distributed carries the
+    # rendezvous token and the timing barriers only.  If the RCCL communicator cannot be formed the same exchange runs
+    # host-staged over a gloo group, and the JSON line says so.
+    comm, collective = None, None
+    if world > 1:
+        try:
+            comm = HvsComm.from_process_group(device=local_rank, transport="rccl")
+            collective = "rccl (ncclAllGather in libhvs)"
+        except hvs.HvsError as e:
+            print(f"[rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = HvsComm.from_process_group(device=local_rank, group=dist.new_group(backend="gloo"), transport="host")
+            collective = "host-staged over gloo (RCCL communicator could not be formed)"
 
     lo, hi = shard_range(args.rows, rank, world)
     idx = hvs.HvsIndex(DIM, "f32", device=local_rank)
@@ -341,7 +365,7 @@ def main():
     idx.fill_synthetic(hi - lo, seed=SEED_CORPUS, first_global_row=lo)
     gen = torch.Generator(device=dev).manual_seed(SEED_QUERY)
     queries = torch.randn((args.batch, DIM), device=dev, dtype=torch.float32, generator=gen)
-    searcher = ShardedSearch.for_index(idx, None)
+    searcher = ShardedSearch.for_index(idx, comm)
 
     def step():
         return searcher.search(queries, TOPK, algo="mfma_f32")
@@ -401,12 +425,13 @@ def main():
             "config": {
                 "workload": f"{args.rows} x {DIM} fp32 corpus row-sharded over {world} GPU(s), batches of "
                             f"{args.batch} queries, exact cosine top-{TOPK} (fp32 MFMA GEMM + fused top-k, "
-                            f"RCCL all-gather merge)",
+                            f"one packed all-gather + merge per batch)",
                 "rows": args.rows,
                 "dim": DIM,
                 "batch": args.batch,
                 "k": TOPK,
                 "parallelism": f"row-shard x{world}",
+                "collective": collective,
             },
             "roofline": {
                 "bound": "mfma",

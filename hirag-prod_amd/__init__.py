@@ -5,7 +5,7 @@ directory).  Public surface:
 
 * ``HvsIndex``        -- one embedded table resident in HBM (``index.py``)
 * ``HipVectorStore``  -- drop-in for the reference's ``BaseVDB`` / ``PGVector`` (``store.py``)
-* ``ShardedSearch`` / ``sharded_kmeans_step`` -- one process per GPU over RCCL (``sharded.py``)
+* ``HvsComm`` / ``ShardedSearch`` / ``sharded_kmeans_step`` -- one process per GPU over RCCL (``sharded.py``)
 * ``HvsGraph``        -- knowledge graph in HBM + personalised PageRank (``graph.py``)
 * ``HipGraphStore`` / ``FusionQueryService`` -- graph tables and the fusion step after retrieval (``graph_store.py``)
 """
@@ -34,7 +34,7 @@ def __getattr__(name):
         from . import cluster_filter
 
         return getattr(cluster_filter, name)
-    if name in ("ShardedSearch", "sharded_kmeans_step", "shard_range"):
+    if name in ("ShardedSearch", "HvsComm", "host_exchange", "sharded_kmeans_step", "shard_range"):
         from . import sharded
 
         return getattr(sharded, name)

@@ -26,6 +26,12 @@ DTYPE_CODE = {"f32": HVS_F32, "f16": HVS_F16, "bf16": HVS_BF16}
 ALGO_CODE = {"auto": HVS_ALGO_AUTO, "scan": HVS_ALGO_SCAN, "mfma": HVS_ALGO_MFMA, "mfma_f32": HVS_ALGO_MFMA_F32,
              "mfma_split": HVS_ALGO_MFMA_SPLIT}
 
+HVS_UNIQUE_ID_BYTES = 128
+HVS_REDUCE_I64 = 100
+# the host-staged transport's exchange functions (hvs_allgather_fn / hvs_allreduce_fn)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int)
+
 # name -> (restype, argtypes): every symbol include/hvs.h declares
 SIGNATURES = {
     "hvs_last_error": (c_char_p, []),
@@ -51,6 +57,16 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "hvs_comm_unique_id": (c_int, [c_void_p, c_int]),
+    "hvs_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, c_char_p, c_int]),
+    "hvs_comm_init_host": (c_int, [POINTER(c_void_p), c_int, c_int, ALLGATHER_FN, ALLREDUCE_FN, c_void_p]),
+    "hvs_comm_destroy": (c_int, [c_void_p]),
+    "hvs_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "hvs_search_sharded": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    ),
+    "hvs_allreduce_centroids": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]),
     "hvs_distances": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int]),
     "hvs_gather": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int]),
     "hvs_merge_topk": (

@@ -117,6 +117,9 @@ int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, 
 int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacity, float *d_out_dist, int64_t *d_out_ids,
                       int64_t *total);
 
+int hvs_merge_launch(hipStream_t st, const float *in_dist, const int64_t *in_ids, const int32_t *in_count, int nq, int P, int k,
+                     int64_t dist_q, int64_t dist_p, int64_t ids_q, int64_t ids_p, int64_t cnt_q, int64_t cnt_p, float *out_dist,
+                     int64_t *out_ids, int32_t *out_count);  // hvs_scan.hip
 int hvs_noalloc_setup(int device);  // hvs_scan.hip: address of the scratch array of hvs_search_noalloc on `device` (current)
 
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,

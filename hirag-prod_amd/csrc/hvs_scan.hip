@@ -1138,8 +1138,13 @@ extern "C" int hvs_range_search(hvs_index *idx, const float *queries, int fold, 
 // ---- cross-GPU merge ----------------------------------------------------------------------------
 // (dist, id) lists -> keys are not usable here (ids are 64-bit), so this kernel orders pairs directly.
 // One wave per query; candidates = P*k pairs; selection by rank counting in chunks through LDS.
+// List pl of query q starts at in_dist[q * dist_q + pl * dist_p] (likewise ids and counts): [nq, P, k] arrays and the
+// per-rank records of a packed all-gather are both such layouts.
+struct MergeStrides {
+    int64_t dist_q, dist_p, ids_q, ids_p, cnt_q, cnt_p;
+};
 __global__ __launch_bounds__(64) void merge_pairs_kernel(const float *__restrict__ in_dist, const int64_t *__restrict__ in_ids,
-                                                          const int32_t *__restrict__ in_count, int P, int k,
+                                                          const int32_t *__restrict__ in_count, int P, int k, MergeStrides ms,
                                                           float *out_dist, int64_t *out_ids, int32_t *out_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: sorted list of k (dist, id) pairs
@@ -1149,9 +1154,10 @@ __global__ __launch_bounds__(64) void merge_pairs_kernel(const float *__restrict
     const int q = blockIdx.x;
     int cnt = 0;
     for (int pl = 0; pl < P; pl++) {
-        const int c = in_count[(size_t)q * P + pl];
-        const float *sd = in_dist + ((size_t)q * P + pl) * k;
-        const int64_t *si = in_ids + ((size_t)q * P + pl) * k;
+        int c = in_count[(int64_t)q * ms.cnt_q + (int64_t)pl * ms.cnt_p];
+        c = c < 0 ? 0 : (c > k ? k : c);  // a count is data from another rank: never index past a list
+        const float *sd = in_dist + (int64_t)q * ms.dist_q + (int64_t)pl * ms.dist_p;
+        const int64_t *si = in_ids + (int64_t)q * ms.ids_q + (int64_t)pl * ms.ids_p;
         for (int base = 0; base < c; base += 64) {
             const int i = base + lane;
             const bool have = i < c;
@@ -1200,6 +1206,16 @@ __global__ __launch_bounds__(64) void merge_pairs_kernel(const float *__restrict
     if (lane == 0) out_count[q] = cnt;
 }
 
+int hvs_merge_launch(hipStream_t st, const float *in_dist, const int64_t *in_ids, const int32_t *in_count, int nq, int P, int k,
+                     int64_t dist_q, int64_t dist_p, int64_t ids_q, int64_t ids_p, int64_t cnt_q, int64_t cnt_p, float *out_dist,
+                     int64_t *out_ids, int32_t *out_count) {
+    const size_t lds = (((size_t)k * 4 + 15) & ~(size_t)15) + (size_t)k * 8;
+    const MergeStrides ms{dist_q, dist_p, ids_q, ids_p, cnt_q, cnt_p};
+    merge_pairs_kernel<<<nq, 64, lds, st>>>(in_dist, in_ids, in_count, P, k, ms, out_dist, out_ids, out_count);
+    HVS_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int64_t *in_ids,
                               const int32_t *in_count, int nq, int P, int k, float *out_dist, int64_t *out_ids,
                               int32_t *out_count) {
@@ -1208,8 +1224,6 @@ extern "C" int hvs_merge_topk(int device_id, void *stream, const float *in_dist,
     HVS_REQUIRE(k >= 1 && k <= HVS_MAX_K, "hvs_merge_topk: k %d not in [1, %d]", k, HVS_MAX_K);
     HVS_REQUIRE(in_dist && in_ids && in_count && out_dist && out_ids && out_count, "hvs_merge_topk: NULL argument");
     HVS_HIP(hipSetDevice(device_id));
-    const size_t lds = (((size_t)k * 4 + 15) & ~(size_t)15) + (size_t)k * 8;
-    merge_pairs_kernel<<<nq, 64, lds, (hipStream_t)stream>>>(in_dist, in_ids, in_count, P, k, out_dist, out_ids, out_count);
-    HVS_HIP(hipGetLastError());
-    return 0;
+    return hvs_merge_launch((hipStream_t)stream, in_dist, in_ids, in_count, nq, P, k, (int64_t)P * k, k, (int64_t)P * k, k, P, 1, out_dist,
+                            out_ids, out_count);
 }

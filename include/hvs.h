@@ -247,6 +247,52 @@ int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int6
                    float *out_dist, int64_t *out_ids, int32_t *out_count);
 
 /*
+ * ---- row shards over the GPUs of one node: one process per GPU, one communicator per process ----
+ * The reference is single-node (one PostgreSQL server) and has no counterpart to any of these.  Each rank holds a
+ * contiguous row range of the table in its own hvs_index, with global row numbers as ids; queries and centroids are
+ * replicated.
+ *
+ * hvs_comm_unique_id: rank 0 makes the HVS_UNIQUE_ID_BYTES rendezvous token (ncclGetUniqueId) and the caller hands it
+ * to every rank by whatever channel it has (a file, MPI, torch.distributed).  hvs_comm_init: ncclCommInitRank on
+ * device_id -- RCCL over xGMI, the product transport; collective on all ranks.  librccl is opened on first use
+ * (HVS_RCCL_PATH, $ROCM_PATH/lib, /opt/rocm/lib).
+ * hvs_comm_init_host: the same exchanges through two caller-supplied functions over HOST buffers, for ranks that cannot
+ * form an RCCL communicator (processes sharing one GPU, a process group without device collectives).
+ *   allgather(ctx, send, recv, bytes): every rank contributes `bytes` bytes; recv = the W contributions in rank order.
+ *   allreduce(ctx, buf, count, dtype): element-wise sum over the ranks, in place; dtype HVS_F32 (float) or
+ *     HVS_REDUCE_I64 (int64_t).
+ *   Both return 0 on success.
+ */
+typedef struct hvs_comm hvs_comm;
+#define HVS_UNIQUE_ID_BYTES 128
+#define HVS_REDUCE_I64 100
+typedef int (*hvs_allgather_fn)(void *ctx, const void *send, void *recv, uint64_t bytes_per_rank);
+typedef int (*hvs_allreduce_fn)(void *ctx, void *buf, uint64_t count, int dtype);
+int hvs_comm_unique_id(void *out, int bytes);
+int hvs_comm_init(hvs_comm **out, int rank, int world, const void *unique_id, int device_id);
+int hvs_comm_init_host(hvs_comm **out, int rank, int world, hvs_allgather_fn allgather,
+                       hvs_allreduce_fn allreduce, void *ctx);
+int hvs_comm_destroy(hvs_comm *comm);
+int hvs_comm_info(hvs_comm *comm, int *rank, int *world, int *is_rccl);
+
+/*
+ * hvs_search over a row-sharded table: the local search of this rank's index (arguments as hvs_search, whole index),
+ * ONE all-gather of every rank's packed (distances, ids, counts) record -- k * 12 + 4 bytes per query and rank -- and a
+ * k-way merge by (distance, id) on every rank, all on the index's stream.  Every rank calls it with the same queries and
+ * gets the same answer, which equals the single-index answer over the whole table.  Collective.
+ */
+int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *queries, int nq, int fold, int k,
+                       int32_t group_filter, const uint32_t *row_mask, double max_distance,
+                       float *out_dist, int64_t *out_ids, int32_t *out_count, int on_device, int algo);
+
+/*
+ * Sum the k-means partial sums [n_centroids, dim] and counts [n_centroids] of hvs_kmeans_assign over the ranks, in
+ * place (25.2 MB at 4096 centroids of 1536 columns); on return with on_device = 1 the work is complete for the host
+ * transport and submitted to the index's stream for RCCL.  Collective.
+ */
+int hvs_allreduce_centroids(hvs_index *idx, hvs_comm *comm, float *sums, int64_t *counts, int n_centroids, int on_device);
+
+/*
  * Dense cosine-similarity matrix of two small row sets: out[i, j] =
  * a_i . b_j / (|a_i| |b_j|), and 0 where either norm is 0 (scikit-learn's
  * cosine_similarity).  a is float [m, dim], b float [n, dim], out float [m, n],

@@ -1,7 +1,10 @@
-"""CPU tier: the N > 1 exchange logic (row shards, all-gather, merge, centroid all-reduce) on two
-``gloo`` ranks.  Local search / assignment and the merge are oracle-backed test doubles here; the
-product wires the HIP kernels (``ShardedSearch.for_index``)."""
+"""CPU tier: the N > 1 exchange plumbing on two ``gloo`` ranks.  What crosses between ranks on the host-staged
+transport of ``hvs_comm`` are the two callbacks of ``hirag_prod_amd.sharded.host_exchange``; here they are invoked as
+the C side invokes them (through their ctypes function pointers, on raw buffers), with the per-rank records built from
+the oracle's answers, and the merged result is checked against the oracle over the whole corpus.  The GPU tier runs the
+same exchange under the real kernels (tests/test_gpu_sharded.py)."""
 
+import ctypes
 import os
 import socket
 
@@ -20,92 +23,123 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _merge_cpu(d, i, c, k):
-    """[nq, P, k] lists -> [nq, k] by (distance, id): same contract as hvs_merge_topk."""
-    nq, P, _ = d.shape
-    od = torch.full((nq, k), float("inf"))
-    oi = torch.full((nq, k), -1, dtype=torch.int64)
-    oc = torch.zeros(nq, dtype=torch.int32)
-    for q in range(nq):
-        pairs = []
-        for p in range(P):
-            for j in range(int(c[q, p])):
-                pairs.append((float(d[q, p, j]), int(i[q, p, j])))
-        pairs.sort()
-        pairs = pairs[:k]
-        oc[q] = len(pairs)
-        for j, (dd, ii) in enumerate(pairs):
-            od[q, j] = dd
-            oi[q, j] = ii
-    return od, oi, oc
-
-
 def _worker(rank, world, port, n, dim, k, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from hirag_prod_amd.sharded import ShardedSearch, shard_range, sharded_kmeans_step
+    from hirag_prod_amd import _lib
+    from hirag_prod_amd.sharded import host_exchange, shard_range
 
+    allgather, allreduce = host_exchange(None)
     rows = po.synth_rows(1234, 0, n, dim)
     rows[10] = rows[n - 5]  # a cross-shard tie: the lower global id must come first
     lo, hi = shard_range(n, rank, world)
     queries = po.synth_rows(4321, 0, 6, dim)
     queries[0] = rows[10]
-
-    def local_search(q, kk, **kw):
-        q = q.numpy()
-        d = torch.full((q.shape[0], kk), float("inf"))
-        i = torch.full((q.shape[0], kk), -1, dtype=torch.int64)
-        c = torch.zeros(q.shape[0], dtype=torch.int32)
-        for j in range(q.shape[0]):
-            idx, dd = po.query(rows[lo:hi], q[j], k=kk, threshold=kw.get("max_distance"))
-            c[j] = len(idx)
-            i[j, : len(idx)] = torch.from_numpy(idx + lo)  # global ids
-            d[j, : len(idx)] = torch.from_numpy(dd.astype(np.float32))
-        return d, i, c
-
-    s = ShardedSearch(local_search, _merge_cpu)
-    d, i, c = s.search(torch.from_numpy(queries), k)
-    d2, i2, c2 = s.search(torch.from_numpy(queries), k, max_distance=0.97)
-
-    cents = torch.from_numpy(rows[:7].copy())
-
-    def assign_fn(cc):
-        a, _ = kmeans_oracle.assign(rows[lo:hi], cc.numpy())
-        _, sums, counts = kmeans_oracle.update(rows[lo:hi], a, cc.numpy())
-        return torch.from_numpy(a), torch.from_numpy(sums.astype(np.float32)), torch.from_numpy(counts)
-
-    new_c, a, counts = sharded_kmeans_step(assign_fn, cents)
-    torch.save({"d": d, "i": i, "c": c, "d2": d2, "i2": i2, "c2": c2, "new_c": new_c, "a": a, "counts": counts,
-                "lo": lo, "hi": hi}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # this rank's record, laid out as hvs_search_sharded packs it: [nq, k] f32 | [nq, k] i64 | [nq] i32
+    nq = queries.shape[0]
+    rec = np.zeros(nq * k * 12 + nq * 4, dtype=np.uint8)
+    d = rec[: nq * k * 4].view(np.float32).reshape(nq, k)
+    i = rec[nq * k * 4 : nq * k * 12].view(np.int64).reshape(nq, k)
+    c = rec[nq * k * 12 :].view(np.int32)
+    d[:] = np.inf
+    i[:] = -1
+    for j in range(nq):
+        idx, dd = po.query(rows[lo:hi], queries[j], k=k, threshold=0.97)
+        c[j] = len(idx)
+        i[j, : len(idx)] = idx + lo
+        d[j, : len(idx)] = dd.astype(np.float32)
+    recv = np.zeros(world * rec.size, dtype=np.uint8)
+    rc = allgather(None, rec.ctypes.data, recv.ctypes.data, rec.size)
+    assert rc == 0
+    # k-means partial sums through the all-reduce callback
+    cents = rows[:7].copy()
+    a, _ = kmeans_oracle.assign(rows[lo:hi], cents)
+    _, sums, counts = kmeans_oracle.update(rows[lo:hi], a, cents)
+    sums = np.ascontiguousarray(sums, dtype=np.float32)
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    assert allreduce(None, sums.ctypes.data, sums.size, _lib.HVS_F32) == 0
+    assert allreduce(None, counts.ctypes.data, counts.size, _lib.HVS_REDUCE_I64) == 0
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), recv=recv, rec_bytes=rec.size, sums=sums, counts=counts, a=a, lo=lo, hi=hi)
     dist.destroy_process_group()
 
 
-def test_two_rank_search_and_kmeans(tmp_path):
+def _merge(recv, rec_bytes, world, nq, k):
+    out = []
+    for j in range(nq):
+        pairs = []
+        for r in range(world):
+            rec = recv[r * rec_bytes : (r + 1) * rec_bytes]
+            d = rec[: nq * k * 4].view(np.float32).reshape(nq, k)
+            i = rec[nq * k * 4 : nq * k * 12].view(np.int64).reshape(nq, k)
+            c = rec[nq * k * 12 :].view(np.int32)
+            pairs += [(float(d[j, t]), int(i[j, t])) for t in range(int(c[j]))]
+        out.append(sorted(pairs)[:k])
+    return out
+
+
+def test_two_rank_exchange_callbacks(tmp_path):
     n, dim, k, world = 3001, 48, 10, 2
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, dim, k, str(tmp_path)), nprocs=world, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt")
-    r1 = torch.load(tmp_path / "rank1.pt")
-    assert (r0["lo"], r0["hi"], r1["lo"], r1["hi"]) == (0, 1501, 1501, 3001)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 1501, 1501, 3001)
+    assert np.array_equal(r0["recv"], r1["recv"])  # every rank holds every record, in rank order
     rows = po.synth_rows(1234, 0, n, dim)
     rows[10] = rows[n - 5]
     queries = po.synth_rows(4321, 0, 6, dim)
     queries[0] = rows[10]
-    for r in (r0, r1):  # every rank holds the merged result
-        for j in range(6):
-            idx, dd = po.query(rows, queries[j], k=k, threshold=None)
-            assert r["i"][j].tolist() == idx.tolist()
-            np.testing.assert_allclose(r["d"][j].numpy(), dd, atol=1e-6)
-            idx, dd = po.query(rows, queries[j], k=k, threshold=0.97)
-            assert int(r["c2"][j]) == len(idx) and r["i2"][j][: len(idx)].tolist() == idx.tolist()
-        assert r["i"][0][:2].tolist() == [10, n - 5]  # tie across shards: lower global id first
+    merged = _merge(r0["recv"], int(r0["rec_bytes"]), world, 6, k)
+    for j in range(6):
+        idx, dd = po.query(rows, queries[j], k=k, threshold=0.97)
+        assert [p[1] for p in merged[j]] == idx.tolist()
+        np.testing.assert_allclose([p[0] for p in merged[j]], dd, atol=1e-6)
+    assert [p[1] for p in merged[0]][:2] == [10, n - 5]  # tie across shards: lower global id first
     a, _ = kmeans_oracle.assign(rows, rows[:7])
-    new_c, _, counts = kmeans_oracle.update(rows, a, rows[:7])
-    np.testing.assert_array_equal(torch.cat([r0["a"], r1["a"]]).numpy(), a)
+    _, sums, counts = kmeans_oracle.update(rows, a, rows[:7])
+    np.testing.assert_array_equal(np.concatenate([r0["a"], r1["a"]]), a)
     for r in (r0, r1):
-        np.testing.assert_array_equal(r["counts"].numpy(), counts)
-        np.testing.assert_allclose(r["new_c"].numpy(), new_c, atol=1e-5)
+        np.testing.assert_array_equal(r["counts"], counts)
+        np.testing.assert_allclose(r["sums"], sums, rtol=1e-5, atol=1e-4)
+
+
+def test_kmeans_step_division_keeps_empty_clusters():
+    from hirag_prod_amd.sharded import sharded_kmeans_step
+
+    class OneShard:  # stands in for an HvsIndex: the E-step of the oracle
+        def __init__(self, rows):
+            self.rows = rows
+
+        def kmeans_assign(self, c):
+            a, _ = kmeans_oracle.assign(self.rows, c)
+            _, sums, counts = kmeans_oracle.update(self.rows, a, c)
+            return a, sums.astype(np.float32), counts
+
+    rows = po.synth_rows(5, 0, 400, 16)
+    cents = np.concatenate([rows[:3], 1e3 * np.ones((1, 16), np.float32)])  # the last centroid attracts nothing
+    new_c, a, counts = sharded_kmeans_step(OneShard(rows), cents)
+    assert counts[3] == 0 and np.array_equal(new_c[3], cents[3])
+    exp, _, _ = kmeans_oracle.update(rows, a, cents)
+    np.testing.assert_allclose(new_c[:3], exp[:3], atol=1e-5)
+
+
+def test_bench_argument_path_for_two_gpus_stops_at_the_device(tmp_path):
+    """`bench.py --gpus 2` without a launcher names the launcher; under one it reaches the GPU set-up (which a CPU box lacks)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
+    if torch.cuda.is_available():
+        return  # on a GPU box the launcher would start the real benchmark
+    port = _free_port()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    # both ranks parsed their arguments, read RANK / WORLD_SIZE, met in a process group and stopped at the missing device
+    assert r.returncode != 0 and (r.stderr + r.stdout).count("no HIP device visible") >= 2, (r.stderr + r.stdout)[-2000:]
 
 
 def test_shard_range_covers_rows():
