@@ -32,6 +32,16 @@ HVS_REDUCE_I64 = 100
 ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_uint64)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_uint64, c_int)
 
+HVS_MAX_FILTER_URIS = 8192
+
+
+class HvsFilterStruct(ctypes.Structure):
+    """``hvs_filter``: the attribute clauses of a search, evaluated on the GPU."""
+
+    _fields_ = [("group", c_int32), ("workspace", c_int32), ("knowledge_base", c_int32), ("access", c_int32),
+                ("uris", c_void_p), ("n_uris", c_int32)]
+
+
 # name -> (restype, argtypes): every symbol include/hvs.h declares
 SIGNATURES = {
     "hvs_last_error": (c_char_p, []),
@@ -57,6 +67,13 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int32, c_void_p, c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p],
     ),
+    "hvs_index_set_attributes": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hvs_search_filtered": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(HvsFilterStruct), c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int],
+    ),
+    "hvs_range_search_filtered": (c_int, [c_void_p, c_void_p, c_int, POINTER(HvsFilterStruct), c_double, c_int64, c_int64, c_int64, c_void_p,
+                                          c_void_p, POINTER(c_int64), c_int]),
     "hvs_comm_unique_id": (c_int, [c_void_p, c_int]),
     "hvs_comm_init": (c_int, [POINTER(c_void_p), c_int, c_int, c_char_p, c_int]),
     "hvs_comm_init_host": (c_int, [POINTER(c_void_p), c_int, c_int, ALLGATHER_FN, ALLREDUCE_FN, c_void_p]),

@@ -1,5 +1,7 @@
 // Index life cycle, ingest, synthetic fill, gather (C ABI: include/hvs.h).
+#include <algorithm>
 #include <cstdarg>
+#include <vector>
 
 #include "hvs_internal.h"
 
@@ -420,6 +422,127 @@ int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, 
 }
 
 // ---------------------------------------------------------------------------
+// row attributes and the filter's row bitmask
+// ---------------------------------------------------------------------------
+__global__ void set_attrs_kernel(int4 *__restrict__ attrs, int64_t first, int64_t n, const int32_t *__restrict__ ws,
+                                 const int32_t *__restrict__ kb, const int32_t *__restrict__ uri, const uint8_t *__restrict__ priv) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int4 a = attrs[first + i];
+        if (ws) a.x = ws[i];
+        if (kb) a.y = kb[i];
+        if (uri) a.z = uri[i];
+        if (priv) a.w = priv[i] ? 1 : 0;
+        attrs[first + i] = a;
+    }
+}
+
+__global__ void gather_attrs_kernel(const int4 *__restrict__ src, const uint32_t *__restrict__ positions, int64_t n, int4 *__restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[positions[i]];
+}
+
+// One wave per 64 consecutive rows and step: lane i tests row base + i (one coalesced 16-byte load per lane), a ballot
+// makes the two mask words.  The uri codes sit sorted in LDS; membership is a binary search.
+#define FILTER_URIS_LDS 8192
+__global__ __launch_bounds__(256) void filter_mask_kernel(const int4 *__restrict__ attrs, int64_t n, int32_t ws, int32_t kb, int32_t access,
+                                                           const int32_t *__restrict__ uris, int n_uris, uint32_t *__restrict__ mask) {
+    __shared__ int32_t s_uris[FILTER_URIS_LDS];
+    for (int i = threadIdx.x; i < n_uris; i += blockDim.x) s_uris[i] = uris[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_steps = (n + 63) / 64;
+    for (int64_t step = wave; step < n_steps; step += n_waves) {
+        const int64_t row = step * 64 + lane;
+        bool ok = row < n;
+        if (ok) {
+            const int4 a = attrs[row];
+            if (ws >= 0) ok = a.x == ws;
+            if (ok && kb >= 0) ok = a.y == kb;
+            if (ok && access >= 0) ok = (a.w != 0) == (access != 0);
+            if (ok && uris) {
+                int lo = 0, hi = n_uris;  // first entry >= a.z
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_uris[mid] < a.z) lo = mid + 1;
+                    else hi = mid;
+                }
+                ok = lo < n_uris && s_uris[lo] == a.z;
+            }
+        }
+        const uint64_t bits = __ballot(ok);
+        if (lane == 0) {
+            mask[step * 2] = (uint32_t)bits;
+            if (step * 64 + 32 < ((n + 31) / 32) * 32) mask[step * 2 + 1] = (uint32_t)(bits >> 32);
+        }
+    }
+}
+
+int hvs_attrs_ensure(hvs_index *idx) {
+    if (idx->attrs || idx->cap == 0) return 0;
+    HVS_HIP(hipMalloc((void **)&idx->attrs, (size_t)idx->cap * sizeof(int4)));
+    HVS_HIP(hipMemsetAsync(idx->attrs, 0, (size_t)idx->cap * sizeof(int4), idx->stream));
+    return 0;
+}
+
+int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask) {
+    *d_mask = nullptr;
+    HVS_REQUIRE(f->n_uris >= 0 && f->n_uris <= HVS_MAX_FILTER_URIS, "hvs_filter: %d uri codes, at most %d", f->n_uris, HVS_MAX_FILTER_URIS);
+    HVS_REQUIRE(f->n_uris == 0 || f->uris != nullptr, "hvs_filter: n_uris = %d with a NULL list", f->n_uris);
+    static_assert(HVS_MAX_FILTER_URIS <= FILTER_URIS_LDS, "uri list must fit the kernel's LDS array");
+    const bool has_uris = f->uris != nullptr;
+    if (f->workspace < 0 && f->knowledge_base < 0 && f->access < 0 && !has_uris) return 0;
+    if (idx->n == 0) return 0;
+    HVS_TRY(hvs_attrs_ensure(idx));
+    const size_t words = (size_t)((idx->n + 31) / 32);
+    void *m = nullptr, *u = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 8, words * 4 + 8, &m));
+    if (has_uris) {
+        // WHERE uri IN (): an empty list matches nothing -- one code no row can carry keeps the kernel's path uniform
+        std::vector<int32_t> sorted(f->uris, f->uris + f->n_uris);
+        std::sort(sorted.begin(), sorted.end());
+        if (sorted.empty()) sorted.push_back(INT32_MIN);
+        HVS_TRY(hvs_ws_get(idx, 9, sorted.size() * 4, &u));
+        HVS_HIP(hipMemcpyAsync(u, sorted.data(), sorted.size() * 4, hipMemcpyHostToDevice, idx->stream));
+        HVS_HIP(hipStreamSynchronize(idx->stream));  // `sorted` is pageable host memory about to go out of scope
+        filter_mask_kernel<<<grid_for((idx->n + 63) / 64 * 64, 256, 2048), 256, 0, idx->stream>>>(
+            idx->attrs, idx->n, f->workspace, f->knowledge_base, f->access, (const int32_t *)u, (int)sorted.size(), (uint32_t *)m);
+    } else {
+        filter_mask_kernel<<<grid_for((idx->n + 63) / 64 * 64, 256, 2048), 256, 0, idx->stream>>>(
+            idx->attrs, idx->n, f->workspace, f->knowledge_base, f->access, nullptr, 0, (uint32_t *)m);
+    }
+    HVS_HIP(hipGetLastError());
+    *d_mask = (const uint32_t *)m;
+    return 0;
+}
+
+extern "C" int hvs_index_set_attributes(hvs_index *idx, int64_t first_pos, int64_t n, const int32_t *workspace,
+                                        const int32_t *knowledge_base, const int32_t *uri, const uint8_t *is_private) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_set_attributes: idx is NULL");
+    HVS_REQUIRE(first_pos >= 0 && n >= 0 && first_pos + n <= idx->n, "hvs_index_set_attributes: rows [%lld, %lld) outside [0, %lld)",
+                (long long)first_pos, (long long)(first_pos + n), (long long)idx->n);
+    if (n == 0 || (!workspace && !knowledge_base && !uri && !is_private)) return 0;
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_TRY(hvs_attrs_ensure(idx));
+    // staging (workspace 3): the four host arrays, 256-byte aligned
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t col = up((size_t)n * 4);
+    void *stage = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 3, 3 * col + up((size_t)n), &stage));
+    char *b = (char *)stage;
+    const int32_t *d_ws = nullptr, *d_kb = nullptr, *d_uri = nullptr;
+    const uint8_t *d_priv = nullptr;
+    if (workspace) { HVS_HIP(hipMemcpyAsync(b, workspace, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream)); d_ws = (const int32_t *)b; }
+    if (knowledge_base) { HVS_HIP(hipMemcpyAsync(b + col, knowledge_base, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream)); d_kb = (const int32_t *)(b + col); }
+    if (uri) { HVS_HIP(hipMemcpyAsync(b + 2 * col, uri, (size_t)n * 4, hipMemcpyHostToDevice, idx->stream)); d_uri = (const int32_t *)(b + 2 * col); }
+    if (is_private) { HVS_HIP(hipMemcpyAsync(b + 3 * col, is_private, (size_t)n, hipMemcpyHostToDevice, idx->stream)); d_priv = (const uint8_t *)(b + 3 * col); }
+    set_attrs_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->attrs, first_pos, n, d_ws, d_kb, d_uri, d_priv);
+    HVS_HIP(hipGetLastError());
+    HVS_HIP(hipStreamSynchronize(idx->stream));  // the host arrays may be released on return
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
 extern "C" int hvs_index_create(hvs_index **out, int device_id, int dim, int dtype, void *stream) {
@@ -468,6 +591,7 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
     hipFree(idx->ids);
     hipFree(idx->groups);
     hipFree(idx->deleted);
+    hipFree(idx->attrs);
     hipFree(idx->split);
     hipFree(idx->split_inv);
     for (auto &w : idx->ws) hipFree(w.ptr);
@@ -518,6 +642,7 @@ extern "C" int hvs_index_reserve(hvs_index *idx, int64_t capacity_rows) {
     HVS_TRY(grow(idx, &idx->groups, (size_t)idx->n, (size_t)capacity_rows));
     if (idx->deleted)
         HVS_TRY(grow(idx, &idx->deleted, (size_t)(idx->cap + 31) / 32, (size_t)(capacity_rows + 31) / 32, true));
+    if (idx->attrs) HVS_TRY(grow(idx, &idx->attrs, (size_t)idx->cap, (size_t)capacity_rows, true));
     idx->cap = capacity_rows;
     return 0;
 }
@@ -624,6 +749,25 @@ extern "C" int hvs_index_add(hvs_index *idx, const void *rows, int src_dtype, in
     return 0;
 }
 
+// positions that arrive in device memory cannot be read by the host: a kernel checks them before anything uses them
+__global__ void check_positions_kernel(const int64_t *__restrict__ positions, int64_t n, int64_t limit, int *__restrict__ bad) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (positions[i] < 0 || positions[i] >= limit) *bad = 1;  // every writer stores the same value
+}
+
+static int validate_device_positions(hvs_index *idx, const int64_t *d_pos, int64_t n, const char *who) {
+    void *flag = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 5, 256, &flag));
+    HVS_HIP(hipMemsetAsync(flag, 0, 4, idx->stream));
+    check_positions_kernel<<<grid_for(n), 256, 0, idx->stream>>>(d_pos, n, idx->n, (int *)flag);
+    HVS_HIP(hipGetLastError());
+    int bad = 0;
+    HVS_HIP(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    HVS_REQUIRE(bad == 0, "%s: a position lies outside [0, %lld)", who, (long long)idx->n);
+    return 0;
+}
+
 extern "C" int hvs_index_update(hvs_index *idx, const int64_t *positions, const void *rows, int src_dtype, int64_t n,
                                 int on_device) {
     HVS_REQUIRE(idx != nullptr, "hvs_index_update: idx is NULL");
@@ -633,6 +777,7 @@ extern "C" int hvs_index_update(hvs_index *idx, const int64_t *positions, const 
     HVS_HIP(hipSetDevice(idx->device));
     const size_t src_row_bytes = (size_t)idx->dim * hvs_elem_size(src_dtype);
     if (on_device) {
+        HVS_TRY(validate_device_positions(idx, positions, n, "hvs_index_update"));
         HVS_TRY(store_rows_device(idx, rows, src_dtype, n, 0, positions));
         return 0;
     }
@@ -686,7 +831,9 @@ extern "C" int hvs_index_prepare(hvs_index *idx, int *out_ready) {
     HVS_HIP(hipSetDevice(idx->device));
     bool ok = false;
     if (idx->dtype == HVS_F32 && idx->n > 0 && !getenv("HVS_NO_SPLIT")) {
+        idx->split_failed = false;  // an explicit request tries again: memory may have been freed since the copy was refused
         HVS_TRY(hvs_split_ensure(idx, &ok));
+        if (!ok) hvs_set_error("hvs_index_prepare: %s", idx->split_why.c_str());  // readable through hvs_last_error; the call still succeeds
         HVS_HIP(hipStreamSynchronize(idx->stream));
     }
     if (out_ready) *out_ready = ok ? 1 : 0;
@@ -736,9 +883,20 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
         float *inv = nullptr;
         int64_t *ids = nullptr;
         int32_t *groups = nullptr;
+        int4 *attrs = nullptr;
         int rc = 0;
         do {  // new arrays sized for the survivors; the old ones are released only when every copy has succeeded
             hipError_t e;
+            if (idx->attrs && (e = hipMalloc((void **)&attrs, (size_t)cap * sizeof(int4))) != hipSuccess) {
+                hvs_set_error("hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
+                rc = 1;
+                break;
+            }
+            if (attrs && (e = hipMemsetAsync(attrs, 0, (size_t)cap * sizeof(int4), idx->stream)) != hipSuccess) {
+                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
+                rc = 1;
+                break;
+            }
             if ((e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4)) != hipSuccess || (e = hipMalloc((void **)&rows, (size_t)cap * pitch + HVS_ROWS_SLACK)) != hipSuccess ||
                 (e = hipMalloc((void **)&inv, (size_t)cap * 4)) != hipSuccess || (e = hipMalloc((void **)&ids, (size_t)cap * 8)) != hipSuccess ||
                 (e = hipMalloc((void **)&groups, (size_t)cap * 4)) != hipSuccess) {
@@ -755,6 +913,7 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
                 if ((rc = hvs_live_write(idx, lp, positions)) != 0) break;
                 if ((rc = hvs_live_gather(idx, idx->rows, idx->inv_norm, idx->ld * idx->elem_size, positions, n_live, rows, inv)) != 0) break;
                 gather_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->ids, idx->groups, positions, n_live, ids, groups);
+                if (attrs) gather_attrs_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->attrs, positions, n_live, attrs);
                 if (renumber_ids) fill_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(ids, groups, n_live, 0, 0, 0, nullptr, groups);
             }
             if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(idx->stream)) != hipSuccess) {
@@ -768,6 +927,7 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
             (void)hipFree(inv);
             (void)hipFree(ids);
             (void)hipFree(groups);
+            (void)hipFree(attrs);
             return rc;
         }
         (void)hipFree(idx->rows);
@@ -779,10 +939,15 @@ extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_
         idx->inv_norm = inv;
         idx->ids = ids;
         idx->groups = groups;
+        if (attrs) {
+            (void)hipFree(idx->attrs);
+            idx->attrs = attrs;
+        }
         idx->deleted = nullptr;
         idx->n_deleted = 0;
         idx->n = n_live;
         hvs_split_invalidate(idx, 0);
+        idx->split_failed = false;  // the table shrank: the copy may fit now
         idx->cap = cap;
     } else if (renumber_ids && idx->n > 0) {
         fill_meta_kernel<<<grid_for(idx->n), 256, 0, idx->stream>>>(idx->ids, idx->groups, idx->n, 0, 0, 0, nullptr, idx->groups);
@@ -888,7 +1053,8 @@ extern "C" int hvs_gather(hvs_index *idx, const int64_t *positions, int64_t n, f
         d_out = (float *)stage;
         d_pos = (const int64_t *)((char *)stage + pos_off);
         HVS_HIP(hipMemcpyAsync((void *)d_pos, positions, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
-    }
+    } else
+        HVS_TRY(validate_device_positions(idx, positions, n, "hvs_gather"));
     const int g = grid_for(n * (int64_t)idx->dim);
     if (idx->dtype == HVS_F32) gather_kernel<float><<<g, 256, 0, idx->stream>>>((const float *)idx->rows, d_pos, n, idx->dim, idx->ld, d_out);
     else if (idx->dtype == HVS_F16) gather_kernel<__half><<<g, 256, 0, idx->stream>>>((const __half *)idx->rows, d_pos, n, idx->dim, idx->ld, d_out);

@@ -61,6 +61,7 @@ struct hvs_index {
     float *inv_norm = nullptr;    // [cap] 1/|row| (+inf for a zero row, so distance becomes NaN)
     int64_t *ids = nullptr;       // [cap] external ids
     int32_t *groups = nullptr;    // [cap] group codes
+    int4 *attrs = nullptr;        // [cap] {workspace code, knowledge-base code, uri code, private flag}; allocated on first use, zero = unset
     uint32_t *deleted = nullptr;  // [ceil(cap/32)] bit set = row deleted; allocated on first delete
     int64_t n_deleted = 0;
     int64_t n = 0;
@@ -71,15 +72,16 @@ struct hvs_index {
     void *split = nullptr;
     float *split_inv = nullptr;
     int64_t split_cap = 0, split_n = 0;
-    bool split_failed = false;  // device memory did not allow the copy
+    bool split_failed = false;  // device memory did not allow the copy (cleared by hvs_index_compact and by an explicit hvs_index_prepare)
+    std::string split_why;      // ... and why, for hvs_index_prepare's caller
     // the filter route learns from its own outcome: after a call in which more than half of the candidate lists proved
     // nothing (a table of tight clusters), the next filter_skip calls go straight to the route that scores every row in
     // full; the run of skipped calls doubles with every failure in a row (4, 8, ... 64) and ends with the first success
     int filter_skip = 0, filter_backoff = 0;
 
-    hvs_workspace ws[8];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
-                          // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,
-                          // 7 candidates of the filter pass (hvs_search_rescore)
+    hvs_workspace ws[10];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
+                           // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,
+                           // 7 candidates of the filter pass (hvs_search_rescore), 8 row bitmask of an hvs_filter, 9 its uri codes
 
     void *h_pin = nullptr;  // pinned host buffer: the results of a search cross to the host in one copy
     size_t h_pin_bytes = 0;
@@ -120,6 +122,17 @@ int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacit
 int hvs_merge_launch(hipStream_t st, const float *in_dist, const int64_t *in_ids, const int32_t *in_count, int nq, int P, int k,
                      int64_t dist_q, int64_t dist_p, int64_t ids_q, int64_t ids_p, int64_t cnt_q, int64_t cnt_p, float *out_dist,
                      int64_t *out_ids, int32_t *out_count);  // hvs_scan.hip
+// Row bitmask of a filter's attribute clauses over rows [0, n) into workspace 8 (*d_mask = nullptr when the filter has
+// none; the group clause stays with the kernels' own group test).  hvs_index.hip
+int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask);
+int hvs_attrs_ensure(hvs_index *idx);
+// hvs_search / hvs_range_search with a row mask that already lies on the device whatever on_device says (hvs_scan.hip)
+int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter, const uint32_t *row_mask,
+                    bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, float *out_dist, int64_t *out_ids,
+                    int32_t *out_count, int on_device, int algo);
+int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_t group_filter, const uint32_t *row_mask,
+                          bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity,
+                          float *out_dist, int64_t *out_ids, int64_t *out_total, int on_device);
 int hvs_noalloc_setup(int device);  // hvs_scan.hip: address of the scratch array of hvs_search_noalloc on `device` (current)
 
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,

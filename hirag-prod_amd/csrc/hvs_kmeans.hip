@@ -232,11 +232,23 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
                                  float *out_sums, int64_t *out_counts, int on_device) {
     HVS_REQUIRE(idx != nullptr, "hvs_kmeans_assign: idx is NULL");
     HVS_REQUIRE(idx->dtype == HVS_F32, "hvs_kmeans_assign: the index must store f32 rows");
-    HVS_REQUIRE(centroids && out_assign, "hvs_kmeans_assign: NULL argument");
+    HVS_REQUIRE(centroids && (out_assign || idx->n == 0), "hvs_kmeans_assign: NULL argument");
     HVS_REQUIRE(n_centroids >= 1, "hvs_kmeans_assign: need at least one centroid");
     HVS_REQUIRE((out_sums == nullptr) == (out_counts == nullptr), "hvs_kmeans_assign: pass both out_sums and out_counts or neither");
     const int64_t n = idx->n;
     if (n == 0) {
+        // an empty shard still owes its all-reduce partner zeros, not whatever the buffers held
+        if (out_sums) {
+            const size_t sum_bytes = (size_t)n_centroids * idx->dim * 4, cnt_bytes = (size_t)n_centroids * 8;
+            if (on_device) {
+                HVS_HIP(hipSetDevice(idx->device));
+                HVS_HIP(hipMemsetAsync(out_sums, 0, sum_bytes, idx->stream));
+                HVS_HIP(hipMemsetAsync(out_counts, 0, cnt_bytes, idx->stream));
+            } else {
+                memset(out_sums, 0, sum_bytes);
+                memset(out_counts, 0, cnt_bytes);
+            }
+        }
         return 0;
     }
     HVS_HIP(hipSetDevice(idx->device));

@@ -834,6 +834,26 @@ bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k);
 extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter,
                           const uint32_t *row_mask, double max_distance, int64_t row_begin, int64_t row_end,
                           float *out_dist, int64_t *out_ids, int32_t *out_count, int on_device, int algo) {
+    return hvs_search_core(idx, queries, nq, fold, k, group_filter, row_mask, on_device != 0, max_distance, row_begin, row_end, out_dist,
+                           out_ids, out_count, on_device, algo);
+}
+
+extern "C" int hvs_search_filtered(hvs_index *idx, const float *queries, int nq, int fold, int k, const hvs_filter *filter,
+                                   double max_distance, int64_t row_begin, int64_t row_end, float *out_dist, int64_t *out_ids,
+                                   int32_t *out_count, int on_device, int algo) {
+    HVS_REQUIRE(idx != nullptr, "hvs_search_filtered: idx is NULL");
+    const uint32_t *d_mask = nullptr;
+    if (filter && nq > 0) {
+        HVS_HIP(hipSetDevice(idx->device));
+        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask));
+    }
+    return hvs_search_core(idx, queries, nq, fold, k, filter ? filter->group : -1, d_mask, true, max_distance, row_begin, row_end, out_dist,
+                           out_ids, out_count, on_device, algo);
+}
+
+int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter, const uint32_t *row_mask,
+                    bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, float *out_dist, int64_t *out_ids,
+                    int32_t *out_count, int on_device, int algo) {
     HVS_REQUIRE(idx != nullptr, "hvs_search: idx is NULL");
     HVS_REQUIRE(nq >= 0, "hvs_search: negative query count");
     if (nq == 0) return 0;
@@ -856,7 +876,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
     int32_t *d_count = out_count;
     const uint32_t *d_mask = row_mask;
     const size_t dist_bytes = (size_t)nq * k * 4, ids_bytes = (size_t)nq * k * 8, cnt_bytes = (size_t)nq * 4;
-    const size_t mask_bytes = row_mask ? (size_t)((idx->n + 31) / 32) * 4 : 0;
+    const size_t mask_bytes = (row_mask && !mask_on_device) ? (size_t)((idx->n + 31) / 32) * 4 : 0;
     if (!on_device) {
         void *stage = nullptr;
         const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
@@ -866,7 +886,7 @@ extern "C" int hvs_search(hvs_index *idx, const float *queries, int nq, int fold
         d_dist = (float *)stage;
         d_ids = (int64_t *)((char *)stage + o_ids);
         d_count = (int32_t *)((char *)stage + o_cnt);
-        if (row_mask) {
+        if (mask_bytes) {
             HVS_HIP(hipMemcpyAsync((char *)stage + o_mask, row_mask, mask_bytes, hipMemcpyHostToDevice, idx->stream));
             d_mask = (const uint32_t *)((char *)stage + o_mask);
         }
@@ -1094,6 +1114,26 @@ extern "C" int hvs_distances(hvs_index *idx, const float *queries, int fold, int
 extern "C" int hvs_range_search(hvs_index *idx, const float *queries, int fold, int32_t group_filter, const uint32_t *row_mask,
                                 double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity, float *out_dist,
                                 int64_t *out_ids, int64_t *out_total, int on_device) {
+    return hvs_range_search_core(idx, queries, fold, group_filter, row_mask, on_device != 0, max_distance, row_begin, row_end, capacity,
+                                 out_dist, out_ids, out_total, on_device);
+}
+
+extern "C" int hvs_range_search_filtered(hvs_index *idx, const float *queries, int fold, const hvs_filter *filter, double max_distance,
+                                         int64_t row_begin, int64_t row_end, int64_t capacity, float *out_dist, int64_t *out_ids,
+                                         int64_t *out_total, int on_device) {
+    HVS_REQUIRE(idx != nullptr, "hvs_range_search_filtered: idx is NULL");
+    const uint32_t *d_mask = nullptr;
+    if (filter) {
+        HVS_HIP(hipSetDevice(idx->device));
+        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask));
+    }
+    return hvs_range_search_core(idx, queries, fold, filter ? filter->group : -1, d_mask, true, max_distance, row_begin, row_end, capacity,
+                                 out_dist, out_ids, out_total, on_device);
+}
+
+int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_t group_filter, const uint32_t *row_mask,
+                          bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity,
+                          float *out_dist, int64_t *out_ids, int64_t *out_total, int on_device) {
     HVS_REQUIRE(idx != nullptr, "hvs_range_search: idx is NULL");
     HVS_REQUIRE(queries && out_total, "hvs_range_search: NULL argument");
     HVS_REQUIRE(capacity >= 0 && (capacity == 0 || (out_dist && out_ids)), "hvs_range_search: outputs missing for capacity %lld", (long long)capacity);
@@ -1105,7 +1145,7 @@ extern "C" int hvs_range_search(hvs_index *idx, const float *queries, int fold, 
         HVS_HIP(hipSetDevice(idx->device));
         const int64_t n_rows = row_end - row_begin;
         // staging (workspace 3): [distance column][mask words, if they come from the host][outputs, if they go to the host]
-        const size_t mask_bytes = (row_mask && !on_device) ? (size_t)((idx->n + 31) / 32) * 4 : 0;
+        const size_t mask_bytes = (row_mask && !mask_on_device) ? (size_t)((idx->n + 31) / 32) * 4 : 0;
         const size_t o_mask = ((size_t)n_rows * 4 + 255) & ~(size_t)255;
         const size_t o_dist = (o_mask + mask_bytes + 255) & ~(size_t)255;
         const size_t o_ids = (o_dist + (on_device ? 0 : (size_t)capacity * 4) + 255) & ~(size_t)255;

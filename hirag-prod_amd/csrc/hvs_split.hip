@@ -80,8 +80,15 @@ int hvs_split_ensure(hvs_index *idx, bool *ok) {
         const size_t need = (size_t)cap * pitch + HVS_ROWS_SLACK + (size_t)cap * 4;
         size_t free_b = 0, total_b = 0;
         HVS_HIP(hipMemGetInfo(&free_b, &total_b));
-        if (free_b < need + ((size_t)8 << 30)) {  // leave room for the search's own buffers
+        // leave room for the searches' own buffers: candidate lists and staging are a few hundred MB even for
+        // 4096-query batches; 1/16 of the copy, at least 1 GiB
+        const size_t headroom = need / 16 > ((size_t)1 << 30) ? need / 16 : ((size_t)1 << 30);
+        if (free_b < need + headroom) {
             idx->split_failed = true;
+            char why[256];
+            snprintf(why, sizeof(why), "the split copy needs %.2f GB plus %.2f GB of headroom, the device has %.2f GB free; searches stay on the fp32 kernels",
+                     need / 1e9, headroom / 1e9, free_b / 1e9);
+            idx->split_why = why;
             return 0;
         }
         char *rows = nullptr;
@@ -91,6 +98,7 @@ int hvs_split_ensure(hvs_index *idx, bool *ok) {
             (void)hipGetLastError();
             if (rows) (void)hipFree(rows);
             idx->split_failed = true;
+            idx->split_why = "hipMalloc of the split copy failed; searches stay on the fp32 kernels";
             return 0;
         }
         const int64_t keep = idx->split ? idx->split_n : 0;

@@ -154,14 +154,51 @@ class HvsIndex:
         with self._lock:
             check(self._lib.hvs_index_fill_clustered(self._h, int(n), int(seed), int(first_global_row), int(n_groups), int(n_clusters)))
 
+    def set_attributes(self, first: int, workspace=None, knowledge_base=None, uri=None, private=None) -> None:
+        """Attribute columns of rows ``[first, first + n)``: int32 codes of workspaceId / knowledgeBaseId / uri and the
+        ``private`` flag, the columns ``hvs_filter`` tests on the GPU (``hvs_index_set_attributes``)."""
+        cols = [None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in (workspace, knowledge_base, uri)]
+        priv = None if private is None else np.ascontiguousarray(private, dtype=np.uint8)
+        lengths = {len(c) for c in cols + [priv] if c is not None}
+        if not lengths:
+            return
+        if len(lengths) != 1:
+            raise ValueError("attribute arrays differ in length")
+        with self._lock:
+            check(self._lib.hvs_index_set_attributes(self._h, int(first), lengths.pop(), _np_ptr(cols[0]), _np_ptr(cols[1]), _np_ptr(cols[2]),
+                                                     _np_ptr(priv)))
+
+    @staticmethod
+    def _filter_struct(filter: dict):
+        """``filter``: keys group / workspace / knowledge_base (codes), access (True = private rows, False = public rows),
+        uris (codes) -- each optional -> (hvs_filter, keepalive)"""
+        unknown = set(filter) - {"group", "workspace", "knowledge_base", "access", "uris"}
+        if unknown:
+            raise ValueError(f"unknown filter keys {sorted(unknown)}")
+        uris = filter.get("uris")
+        uris = None if uris is None else list(uris)
+        # uri IN (): a non-NULL list with zero codes matches nothing, so an empty list still needs an address
+        keep = None if uris is None else np.ascontiguousarray(uris or [0], dtype=np.int32)
+        access = filter.get("access")
+        f = _lib.HvsFilterStruct(int(filter.get("group", -1)), int(filter.get("workspace", -1)), int(filter.get("knowledge_base", -1)),
+                                 -1 if access is None else int(bool(access)), None if keep is None else keep.ctypes.data,
+                                 0 if uris is None else len(uris))
+        return f, keep
+
     # -- search ----------------------------------------------------------------------------------
     def search(self, queries, k: int = 10, fold: int = 1, group_filter: int = -1, row_mask=None,
-               max_distance: float = math.inf, row_begin: int = 0, row_end: int = -1, algo: str = "auto"):
+               max_distance: float = math.inf, row_begin: int = 0, row_end: int = -1, algo: str = "auto", filter: Optional[dict] = None):
         """Exact cosine top-k.  ``queries``: ``[nq*fold, dim]`` float32 (numpy -> numpy results,
         torch on this GPU -> torch results).  Returns ``(dist [nq,k] f32, ids [nq,k] i64, count [nq] i32)``.
+        ``filter`` (see ``_filter_struct``) replaces ``group_filter`` / ``row_mask`` by attribute clauses evaluated
+        on the GPU.
         """
         if algo not in ALGO_CODE:
             raise ValueError(f"algo must be one of {sorted(ALGO_CODE)}")
+        if filter is not None:
+            if row_mask is not None or group_filter >= 0:
+                raise ValueError("give either filter or group_filter / row_mask")
+            return self._search_filtered(queries, k, fold, filter, max_distance, row_begin, row_end, algo)
         if _is_torch(queries):
             import torch
 
@@ -202,6 +239,39 @@ class HvsIndex:
                                        row_begin, row_end, _np_ptr(dist), _np_ptr(ids), _np_ptr(cnt), 0, ALGO_CODE[algo]))
         return dist, ids, cnt
 
+    def _search_filtered(self, queries, k, fold, filter, max_distance, row_begin, row_end, algo):
+        f, keep = self._filter_struct(filter)
+        if _is_torch(queries):
+            import torch
+
+            q = queries.contiguous().to(torch.float32)
+            if q.dim() != 2 or q.shape[1] != self.dim or q.shape[0] % fold:
+                raise ValueError(f"queries must be [nq*fold, {self.dim}]")
+            nq = q.shape[0] // fold
+            torch.cuda.current_stream(q.device).synchronize()
+            dist = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+            ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+            cnt = torch.empty((nq,), dtype=torch.int32, device=q.device)
+            ptrs = [ctypes.c_void_p(t.data_ptr()) for t in (q, dist, ids, cnt)]
+            on_dev = 1
+        else:
+            q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries)), dtype=np.float32)
+            if q.shape[1] != self.dim or q.shape[0] % fold:
+                raise ValueError(f"queries must be [nq*fold, {self.dim}], got {q.shape}")
+            nq = q.shape[0] // fold
+            dist = np.empty((nq, k), dtype=np.float32)
+            ids = np.empty((nq, k), dtype=np.int64)
+            cnt = np.empty((nq,), dtype=np.int32)
+            ptrs = [_np_ptr(a) for a in (q, dist, ids, cnt)]
+            on_dev = 0
+        with self._lock:
+            check(self._lib.hvs_search_filtered(self._h, ptrs[0], nq, fold, k, ctypes.byref(f), float(max_distance), row_begin, row_end,
+                                                ptrs[1], ptrs[2], ptrs[3], on_dev, ALGO_CODE[algo]))
+            if on_dev:
+                check(self._lib.hvs_sync(self._h))
+        del keep
+        return dist, ids, cnt
+
     def distances(self, queries, row_begin: int = 0, row_end: int = -1) -> np.ndarray:
         """``LEAST_j(row <=> q_j)`` for every row of the range (float32, NaN where undefined)."""
         q = np.ascontiguousarray(np.atleast_2d(np.asarray(queries)), dtype=np.float32)
@@ -215,7 +285,7 @@ class HvsIndex:
         return out
 
     def range_search(self, queries, max_distance: float, group_filter: int = -1, row_mask=None, row_begin: int = 0,
-                     row_end: int = -1, capacity: int | None = None):
+                     row_end: int = -1, capacity: int | None = None, filter: Optional[dict] = None):
         """Every live row with ``LEAST_j(row <=> q_j) < max_distance`` in ascending row position: the rows
         the reference keeps from its projected distance column
         (cross_language_search/functions.py:330-340).  Returns ``(dist f32, ids i64, total)``; with a
@@ -230,9 +300,19 @@ class HvsIndex:
                 raise ValueError("row_mask has fewer bits than the index has rows")
         total = ctypes.c_int64(0)
 
+        f = keep = None
+        if filter is not None:
+            if row_mask is not None or group_filter >= 0:
+                raise ValueError("give either filter or group_filter / row_mask")
+            f, keep = self._filter_struct(filter)
+
         def call(cap):
             dist = np.empty((cap,), dtype=np.float32)
             ids = np.empty((cap,), dtype=np.int64)
+            if f is not None:
+                check(self._lib.hvs_range_search_filtered(self._h, _np_ptr(q), q.shape[0], ctypes.byref(f), float(max_distance), row_begin,
+                                                          row_end, cap, _np_ptr(dist), _np_ptr(ids), ctypes.byref(total), 0))
+                return dist, ids
             check(self._lib.hvs_range_search(self._h, _np_ptr(q), q.shape[0], group_filter, _np_ptr(mask), float(max_distance),
                                              row_begin, row_end, cap, _np_ptr(dist), _np_ptr(ids), ctypes.byref(total), 0))
             return dist, ids

@@ -39,6 +39,7 @@ logger = logging.getLogger(__name__)
 _HALF_MAX = 65504.0
 _MAX_FOLD = 8  # HVS_MAX_FOLD
 _MAX_DIST_FOLD = 128  # HVS_MAX_DIST_FOLD: embeddings per call of the distance column / range search
+_MAX_FILTER_URIS = 8192  # HVS_MAX_FILTER_URIS: uri codes a device-evaluated filter takes
 
 
 class StoredVector(list):
@@ -71,6 +72,10 @@ class _Table:
         self.uri_code = np.zeros(0, dtype=np.int32)
         self.private = np.zeros(0, dtype=bool)
         self.live = np.zeros(0, dtype=bool)
+        # row positions change only in compact(): the epoch is odd while one runs and even otherwise; a search whose
+        # epoch moved between its launch and its metadata look-up is run again (PostgreSQL gives the reference snapshot
+        # isolation for the same situation)
+        self.epoch = 0
 
     # -- secondary indexes on scalar columns (documentKey, uri, ...): value -> ascending row positions.
     # Built on first use, kept current by note_insert / note_delete, dropped when positions change.
@@ -373,26 +378,38 @@ class HipVectorStore(BaseVDB):
                 index = self._ensure_index(table, dim)
                 first = len(table.rows)
                 n_new = len(new_rows)
-                table._grow(first + n_new)
                 groups = np.empty(n_new, dtype=np.int32)
+                attrs = np.empty((4, n_new), dtype=np.int32)
                 for j, (pk, row) in enumerate(new_rows):
-                    pos = first + j
                     ws, kb = row.get("workspaceId"), row.get("knowledgeBaseId")
                     groups[j] = self._code(self._group_codes, (ws, kb))
-                    table.group[pos] = groups[j]
-                    table.ws_code[pos] = self._code(self._ws_codes, ws)
-                    table.kb_code[pos] = self._code(self._kb_codes, kb)
-                    table.uri_code[pos] = self._code(self._uri_codes, row.get("uri"))
-                    table.private[pos] = bool(row.get("private", False))
-                    table.live[pos] = True
+                    attrs[0, j] = self._code(self._ws_codes, ws)
+                    attrs[1, j] = self._code(self._kb_codes, kb)
+                    attrs[2, j] = self._code(self._uri_codes, row.get("uri"))
+                    attrs[3, j] = bool(row.get("private", False))
+                # the device first: if it refuses the rows (out of memory, a dimension mismatch) nothing on the host has
+                # changed yet, the keys stay absent and the caller's retry inserts them -- as a rolled-back INSERT would
+                lo, hi = await asyncio.to_thread(self._add_rows, index, np.stack(new_vecs), groups, attrs)
+                if lo != first or hi != first + n_new:
+                    raise RuntimeError(f"table {table_name}: the index put the rows at [{lo}, {hi}), the host table expected "
+                                       f"[{first}, {first + n_new})")
+                table._grow(first + n_new)
+                table.group[first:hi] = groups
+                table.ws_code[first:hi], table.kb_code[first:hi], table.uri_code[first:hi] = attrs[0], attrs[1], attrs[2]
+                table.private[first:hi] = attrs[3] != 0
+                table.live[first:hi] = True
+                for j, (pk, row) in enumerate(new_rows):
                     stored = dict(row)
                     stored.pop("vector", None)  # the vector lives in HBM
                     table.rows.append(stored)
-                    table.pk_map[pk] = pos
-                    table.note_insert(pos, stored)
-                mat = np.stack(new_vecs)
-                lo, hi = await asyncio.to_thread(index.add, mat, None, groups)
-                assert lo == first and hi == first + n_new, "host rows and device rows out of step"
+                    table.pk_map[pk] = first + j
+                    table.note_insert(first + j, stored)
+
+    @staticmethod
+    def _add_rows(index, mat, groups, attrs):
+        lo, hi = index.add(mat, None, groups)
+        index.set_attributes(lo, workspace=attrs[0], knowledge_base=attrs[1], uri=attrs[2], private=attrs[3])
+        return lo, hi
 
     async def upsert_file(self, file, table_name: str = "Files", mode: str = "append"):
         """Insert one Files row unless its primary key exists (pgvector.py:475-503)."""
@@ -444,52 +461,60 @@ class HipVectorStore(BaseVDB):
                 if table.rows[pos] is not None and all(table.rows[pos].get(k) == v for k, v in where.items())
             ]
             if hit:
+                # tombstones on the device first: from then on no search returns these positions, and a search already
+                # under way that does finds the host rows gone and skips them
+                if table.index is not None:
+                    await asyncio.to_thread(table.index.set_deleted, np.asarray(hit, dtype=np.int64), True)
                 for pos in hit:
                     row = table.rows[pos]
                     table.pk_map.pop(tuple(row.get(c) for c in table.pk), None)
                     table.note_delete(pos, row)
                     table.rows[pos] = None
                     table.live[pos] = False
-                if table.index is not None:
-                    await asyncio.to_thread(table.index.set_deleted, np.asarray(hit, dtype=np.int64), True)
         return len(hit) != 0
 
     # -- query -------------------------------------------------------------------------------------
     def _row_filter(self, table: _Table, workspace_id, knowledge_base_id, uri_list, require_access):
-        """-> (group_filter, mask words or None, empty?)  mirroring the WHERE clauses of pgvector.py:573-580."""
-        n = len(table.rows)
-        group_filter = -1
-        keep = None
+        """-> (filter, empty?) mirroring the WHERE clauses of pgvector.py:573-580.  ``filter`` is a hashable tuple
+        (group, workspace, knowledge_base, access, uris) of codes that ``_filter_dict`` turns into what
+        ``HvsIndex.search(filter=...)`` takes: every clause is evaluated on the GPU over the attribute columns."""
+        group = ws = kb = -1
+        access = None
+        uris = None
         has = table.colset.__contains__
         use_ws = bool(workspace_id) and has("workspaceId")
         use_kb = bool(knowledge_base_id) and has("knowledgeBaseId")
         if use_ws and use_kb:
-            code = self._group_codes.get((workspace_id, knowledge_base_id))
-            if code is None:
-                return -1, None, True
-            group_filter = code
+            group = self._group_codes.get((workspace_id, knowledge_base_id))
+            if group is None:
+                return None, True
         elif use_ws or use_kb:
-            codes, arr, key = (self._ws_codes, table.ws_code, workspace_id) if use_ws else (self._kb_codes, table.kb_code, knowledge_base_id)
-            code = codes.get(key)
+            code = (self._ws_codes.get(workspace_id) if use_ws else self._kb_codes.get(knowledge_base_id))
             if code is None:
-                return -1, None, True
-            keep = arr[:n] == code
+                return None, True
+            if use_ws:
+                ws = code
+            else:
+                kb = code
         if uri_list and has("uri"):
-            wanted = [self._uri_codes[u] for u in uri_list if u in self._uri_codes]
-            k2 = np.isin(table.uri_code[:n], np.asarray(wanted, dtype=np.int32))
-            keep = k2 if keep is None else keep & k2
+            uris = tuple(sorted({self._uri_codes[u] for u in uri_list if u in self._uri_codes}))
+            if not uris:
+                return None, True
         if require_access is not None and has("private"):
-            k3 = table.private[:n] == (require_access == "private")
-            keep = k3 if keep is None else keep & k3
-        if keep is None:
-            return group_filter, None, False
-        if not keep.any():
-            return group_filter, None, True
-        bits = np.packbits(keep, bitorder="little")
-        pad = (-len(bits)) % 4
-        if pad:
-            bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
-        return group_filter, bits.view(np.uint32), False
+            access = require_access == "private"
+        return (group, ws, kb, access, uris), False
+
+    @staticmethod
+    def _filter_dict(spec):
+        group, ws, kb, access, uris = spec
+        if ws < 0 and kb < 0 and access is None and uris is None:
+            return None, group  # the pair code alone: the kernels' own group test
+        out = {"group": group, "workspace": ws, "knowledge_base": kb}
+        if access is not None:
+            out["access"] = access
+        if uris is not None:
+            out["uris"] = uris
+        return out, -1
 
     async def query(
         self,
@@ -528,19 +553,27 @@ class HipVectorStore(BaseVDB):
 
         scored: List[dict] = []
         if table.index is not None and len(table.rows):
-            group_filter, mask, empty = self._row_filter(table, workspace_id, knowledge_base_id, uri_list, require_access)
-            if not empty:
-                if self._coalescer is not None and mask is None and q.shape[0] <= _MAX_FOLD:
-                    key = (table_name, int(group_filter), int(topk), int(q.shape[0]), float(distance_threshold))
+            spec, empty = self._row_filter(table, workspace_id, knowledge_base_id, uri_list, require_access)
+            want_vec = "vector" in columns_to_select
+            while not empty:
+                while table.epoch & 1:  # a compaction is renumbering the rows
+                    await asyncio.sleep(0.001)
+                epoch = table.epoch
+                many_uris = spec[4] is not None and len(spec[4]) > _MAX_FILTER_URIS
+                if self._coalescer is not None and q.shape[0] <= _MAX_FOLD and not many_uris:
+                    key = (table_name, spec, int(topk), int(q.shape[0]), float(distance_threshold))
                     pairs = await self._coalescer.submit(key, q)
                 else:
-                    pairs = await asyncio.to_thread(self._search, table, q, int(topk), group_filter, mask, float(distance_threshold))
-                want_vec = "vector" in columns_to_select
+                    pairs = await asyncio.to_thread(self._search, table, q, int(topk), spec, float(distance_threshold))
                 vecs = None
                 if want_vec and pairs:
                     vecs = await asyncio.to_thread(table.index.gather, np.asarray([p for p, _ in pairs], dtype=np.int64))
+                if table.epoch != epoch:
+                    continue  # positions were renumbered under this search: its answer names other rows now
                 for j, (pos, dist) in enumerate(pairs):
-                    row = table.rows[pos]
+                    row = table.rows[pos] if pos < len(table.rows) else None
+                    if row is None:
+                        continue  # deleted between the search and this look-up
                     payload = {}
                     for col in columns_to_select:
                         if col == "vector":
@@ -549,22 +582,47 @@ class HipVectorStore(BaseVDB):
                             payload[col] = row.get(col)
                     payload["distance"] = dist
                     scored.append(payload)
+                break
         logger.info(f"[query] Retrieved {len(scored)} records from '{table_name}', elapsed={time.perf_counter() - start:.3f}s")
         return scored
 
     def _search_batch(self, key: tuple, queries: List[np.ndarray]) -> List[List[tuple]]:
         """Blocking part of coalesced ``query`` calls: requests with the same key in one launch."""
-        table_name, group_filter, topk, fold, threshold = key
+        table_name, spec, topk, fold, threshold = key
         index = self.tables[table_name].index
-        dist, ids, cnt = index.search(np.concatenate(queries, axis=0), k=topk, fold=fold, group_filter=group_filter, max_distance=threshold)
+        filt, group = self._filter_dict(spec)
+        dist, ids, cnt = index.search(np.concatenate(queries, axis=0), k=topk, fold=fold, group_filter=group, filter=filt,
+                                      max_distance=threshold)
         return [[(int(ids[b][i]), float(dist[b][i])) for i in range(int(cnt[b]))] for b in range(len(queries))]
 
-    def _search(self, table: _Table, q: np.ndarray, topk: int, group_filter: int, mask, threshold: float):
+    def _host_mask(self, table: _Table, spec):
+        """Row bitmask built on the host: only for a uri list longer than the device's list buffer holds."""
+        group, ws, kb, access, uris = spec
+        n = len(table.rows)
+        keep = np.isin(table.uri_code[:n], np.asarray(uris, dtype=np.int32))
+        if ws >= 0:
+            keep &= table.ws_code[:n] == ws
+        if kb >= 0:
+            keep &= table.kb_code[:n] == kb
+        if access is not None:
+            keep &= table.private[:n] == access
+        bits = np.packbits(keep, bitorder="little")
+        pad = (-len(bits)) % 4
+        if pad:
+            bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
+        return bits.view(np.uint32)
+
+    def _search(self, table: _Table, q: np.ndarray, topk: int, spec, threshold: float):
         """Blocking part of ``query``: one fused LEAST-fold search (or several for > 8 embeddings)."""
         index = table.index
         m = q.shape[0]
+        if spec[4] is not None and len(spec[4]) > _MAX_FILTER_URIS:
+            kw = {"group_filter": spec[0], "row_mask": self._host_mask(table, spec)}
+        else:
+            filt, group = self._filter_dict(spec)
+            kw = {"group_filter": group, "filter": filt}
         if m <= _MAX_FOLD:
-            dist, ids, cnt = index.search(q, k=topk, fold=m, group_filter=group_filter, row_mask=mask, max_distance=threshold)
+            dist, ids, cnt = index.search(q, k=topk, fold=m, max_distance=threshold, **kw)
             c = int(cnt[0])
             return [(int(ids[0][i]), float(dist[0][i])) for i in range(c)]
         # more embeddings than one launch folds: every row of the final top-k is inside the top-k of
@@ -573,8 +631,7 @@ class HipVectorStore(BaseVDB):
         best: Dict[int, float] = {}
         for s in range(0, m, _MAX_FOLD):
             part = q[s : s + _MAX_FOLD]
-            dist, ids, cnt = index.search(part, k=topk, fold=part.shape[0], group_filter=group_filter, row_mask=mask,
-                                          max_distance=threshold)
+            dist, ids, cnt = index.search(part, k=topk, fold=part.shape[0], max_distance=threshold, **kw)
             for i in range(int(cnt[0])):
                 pos, d = int(ids[0][i]), float(dist[0][i])
                 if pos not in best or d < best[pos]:
@@ -688,19 +745,28 @@ class HipVectorStore(BaseVDB):
         if table.index is None or not len(table.rows) or q.size == 0:
             return []
         if max_distance is not None:
-            group_filter, mask, empty = self._row_filter(table, workspace_id, knowledge_base_id, None, None)
+            spec, empty = self._row_filter(table, workspace_id, knowledge_base_id, None, None)
             if empty:
                 return []
-            best: Dict[int, float] = {}
-            for s in range(0, q.shape[0], _MAX_DIST_FOLD):  # LEAST < bound iff some group's LEAST < bound
-                dist, ids, _ = await asyncio.to_thread(table.index.range_search, q[s : s + _MAX_DIST_FOLD], float(max_distance),
-                                                       group_filter, mask)
-                for pos, d in zip(ids.tolist(), dist.tolist()):
-                    if pos not in best or d < best[pos]:
-                        best[pos] = d
+            filt, group = self._filter_dict(spec)
+            while True:
+                while table.epoch & 1:
+                    await asyncio.sleep(0.001)
+                epoch = table.epoch
+                best: Dict[int, float] = {}
+                for s in range(0, q.shape[0], _MAX_DIST_FOLD):  # LEAST < bound iff some group's LEAST < bound
+                    dist, ids, _ = await asyncio.to_thread(lambda part=q[s : s + _MAX_DIST_FOLD]: table.index.range_search(
+                        part, float(max_distance), group_filter=group, filter=filt))
+                    for pos, d in zip(ids.tolist(), dist.tolist()):
+                        if pos not in best or d < best[pos]:
+                            best[pos] = d
+                if table.epoch == epoch:
+                    break
             out = []
             for pos in sorted(best):
                 row = table.rows[pos]
+                if row is None:
+                    continue
                 rec = {c: row.get(c) for c in columns_to_select if c in table.colset and c != "vector"}
                 rec[column_name] = best[pos]
                 out.append(rec)
@@ -746,14 +812,19 @@ class HipVectorStore(BaseVDB):
                 n = len(table.rows)
                 keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
                 if len(keep) != n:
-                    if table.index is not None:
-                        left = await asyncio.to_thread(table.index.compact, True)
-                        assert left == len(keep), "host rows and device rows out of step"
-                    table.rows = [table.rows[pos] for pos in keep]
-                    for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
-                        setattr(table, col, getattr(table, col)[:n][keep].copy())
-                    table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
-                    table.key_index.clear()
+                    table.epoch += 1  # odd: searches launched from here on wait, those under way will notice and run again
+                    try:
+                        if table.index is not None:
+                            left = await asyncio.to_thread(table.index.compact, True)
+                            if left != len(keep):
+                                raise RuntimeError(f"table {name}: {left} rows left on the device, {len(keep)} on the host")
+                        table.rows = [table.rows[pos] for pos in keep]
+                        for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
+                            setattr(table, col, getattr(table, col)[:n][keep].copy())
+                        table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
+                        table.key_index.clear()
+                    finally:
+                        table.epoch += 1
                 out[name] = len(table.rows)
         return out
 
@@ -851,6 +922,9 @@ class HipVectorStore(BaseVDB):
                     read_index, os.path.join(directory, f"{name}.hvs"), lambda dim, dtype: store._make_index(dim))
                 if len(table.index) != n or table.index.dtype != store.dtype:
                     raise ValueError(f"{directory}: {name}.hvs does not match the store ({len(table.index)} rows, {table.index.dtype})")
+                if n:  # the attribute columns are rebuilt from the metadata rows
+                    await asyncio.to_thread(table.index.set_attributes, 0, table.ws_code[:n], table.kb_code[:n], table.uri_code[:n],
+                                            table.private[:n])
         return store
 
     # -- graph side ----------------------------------------------------------------------------------

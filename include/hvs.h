@@ -89,7 +89,8 @@ int hvs_sync(hvs_index *idx);
 int hvs_index_add(hvs_index *idx, const void *rows, int src_dtype, int64_t n,
                   const int64_t *ids, const int32_t *group_codes, int on_device);
 
-/* Overwrite stored rows in place (positions are row positions, not ids). */
+/* Overwrite stored rows in place (positions are row positions, not ids; they must be distinct within a call and are
+ * range-checked, on the device when they arrive there). */
 int hvs_index_update(hvs_index *idx, const int64_t *positions, const void *rows, int src_dtype,
                      int64_t n, int on_device);
 
@@ -180,6 +181,36 @@ int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k,
                int64_t row_begin, int64_t row_end,
                float *out_dist, int64_t *out_ids, int32_t *out_count,
                int on_device, int algo);
+
+/*
+ * The WHERE clauses of PGVector.query beyond the (workspaceId, knowledgeBaseId) pair (pgvector.py:573-580), evaluated on
+ * the GPU: every row carries four attributes next to its group code -- workspace code, knowledge-base code, uri code
+ * (int32 each) and a private flag -- set with hvs_index_set_attributes after the rows were added (HOST arrays of n
+ * entries for row positions [first_pos, first_pos + n); a NULL array leaves that attribute as it is, attributes never
+ * set read as 0; they move with their rows in hvs_index_compact).  An hvs_filter names the values a row must have;
+ * the searches below evaluate it in one pass over the attribute columns (16 B per row) into a row bitmask on the
+ * device and then run as hvs_search / hvs_range_search do with that mask: no per-query mask is built or uploaded by the
+ * host.  The uri list is a HOST array of at most HVS_MAX_FILTER_URIS codes in any order.
+ */
+typedef struct hvs_filter {
+    int32_t group;          /* code of (workspaceId, knowledgeBaseId), -1 = any */
+    int32_t workspace;      /* WHERE workspaceId = ..      alone, -1 = any */
+    int32_t knowledge_base; /* WHERE knowledgeBaseId = ..  alone, -1 = any */
+    int32_t access;         /* WHERE private = ..: 1 = private rows only, 0 = public rows only, -1 = any */
+    const int32_t *uris;    /* WHERE uri IN (..): codes, NULL = any */
+    int32_t n_uris;
+} hvs_filter;
+#define HVS_MAX_FILTER_URIS 8192
+int hvs_index_set_attributes(hvs_index *idx, int64_t first_pos, int64_t n, const int32_t *workspace,
+                             const int32_t *knowledge_base, const int32_t *uri, const uint8_t *is_private);
+/* hvs_search with the filter in place of group_filter / row_mask (filter NULL = no WHERE) */
+int hvs_search_filtered(hvs_index *idx, const float *queries, int nq, int fold, int k,
+                        const hvs_filter *filter, double max_distance, int64_t row_begin, int64_t row_end,
+                        float *out_dist, int64_t *out_ids, int32_t *out_count, int on_device, int algo);
+/* hvs_range_search likewise */
+int hvs_range_search_filtered(hvs_index *idx, const float *queries, int fold, const hvs_filter *filter,
+                              double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity,
+                              float *out_dist, int64_t *out_ids, int64_t *out_total, int on_device);
 
 /*
  * hvs_search for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that

@@ -450,7 +450,7 @@ async def scenario_concurrent_queries(store, storage):
         thr = 1.3 if j % 2 else 0.9
         calls.append((qs, w, k, thr))
     uris = np.array([p["uri"] for p in props])
-    calls.append((["text ws1 kb1 5"], "ws1", 10, 1.3, [props[5]["uri"]]))  # a bitmask filter: served alone
+    calls.append((["text ws1 kb1 5"], "ws1", 10, 1.3, [props[5]["uri"]]))  # a uri filter: evaluated on the device, queued like the rest
     results = await asyncio.gather(*[
         store.query(c[0], c[1], "kb1", "Chunks", topk=c[2], distance_threshold=c[3], uri_list=c[4] if len(c) > 4 else None) for c in calls])
     for c, res in zip(calls, results):
@@ -460,7 +460,7 @@ async def scenario_concurrent_queries(store, storage):
         idx, dist = expected_hits(texts, keep, c[0], c[2], c[3], storage)
         same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
     co = store._coalescer
-    assert co.requests == 40 and co.launches < 40  # 16 distinct (workspace, k, fold, threshold) keys at most
+    assert co.requests == 41 and co.launches <= 17  # 16 distinct (workspace, k, fold, threshold) keys at most + the uri filter
     # a failing launch reaches every waiter of its batch and leaves the queue usable
     table = store.tables["Chunks"]
     real = table.index
@@ -476,6 +476,96 @@ async def scenario_concurrent_queries(store, storage):
     res = await store.query("text ws1 kb1 4", "ws1", "kb1", "Chunks", distance_threshold=1.3)
     idx, dist = expected_hits(texts, ws == "ws1", ["text ws1 kb1 4"], 10, 1.3, storage)
     same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+
+
+async def scenario_no_host_mask(store, storage):
+    """Every WHERE clause of ``query`` (pgvector.py:573-580) reaches the index as attribute codes: the store never
+    builds a per-query row bitmask for workspace-only, knowledge-base-only, uri_list or require_access filters."""
+    await store._init_vdb(embedding_dimension=DIM)
+    n = 240
+    props = [chunk_props(i, ws=f"ws{i % 3}", kb=f"kb{i % 2}", private=(i % 4 == 0)) for i in range(n)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts, props, "Chunks")
+    index = store.tables["Chunks"].index
+    seen = []
+    real_search = index.search
+
+    def spy(*a, **kw):
+        seen.append(kw)
+        return real_search(*a, **kw)
+
+    index.search = spy
+    ws = np.array([p["workspaceId"] for p in props])
+    kb = np.array([p["knowledgeBaseId"] for p in props])
+    private = np.array([p["private"] for p in props])
+    uris = np.array([p["uri"] for p in props])
+    cases = [
+        (dict(workspace_id="ws1", knowledge_base_id=""), ws == "ws1"),
+        (dict(workspace_id="", knowledge_base_id="kb1"), kb == "kb1"),
+        (dict(workspace_id="ws2", knowledge_base_id="kb0", uri_list=[props[0]["uri"], props[1]["uri"], "s3://unknown"]),
+         (ws == "ws2") & (kb == "kb0") & np.isin(uris, [props[0]["uri"], props[1]["uri"]])),
+        (dict(workspace_id="ws0", knowledge_base_id="kb0", require_access="private"), (ws == "ws0") & (kb == "kb0") & private),
+        (dict(workspace_id="ws0", knowledge_base_id="", require_access="public", uri_list=[props[2]["uri"]]),
+         (ws == "ws0") & ~private & (uris == props[2]["uri"])),
+    ]
+    for kw, keep in cases:
+        res = await store.query("text ws1 kb1 7", table_name="Chunks", topk=15, distance_threshold=1.5, **kw)
+        idx, dist = expected_hits(texts, keep, ["text ws1 kb1 7"], 15, 1.5, storage)
+        same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+    assert len(seen) == len(cases) and all(kw.get("row_mask") is None for kw in seen)
+    assert sum(kw.get("filter") is not None for kw in seen) == len(cases)
+    # a uri nobody has: answered without a launch
+    assert await store.query("x", "ws1", "kb1", "Chunks", uri_list=["s3://unknown"]) == []
+    assert len(seen) == len(cases)
+    index.search = real_search
+
+
+async def scenario_failed_add_and_races(store, storage, make_add_fail):
+    """What PostgreSQL's transactions give the reference: a failed insert leaves nothing behind, and deletes or a
+    vacuum never corrupt a query that is running."""
+    await store._init_vdb(embedding_dimension=DIM)
+    props = [chunk_props(i) for i in range(60)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts[:20], props[:20], "Chunks")
+    table = store.tables["Chunks"]
+    # 1. the device refuses an insert: host state unchanged, the retry inserts the rows
+    make_add_fail(table.index, RuntimeError("hipMalloc failed"))
+    try:
+        await store.upsert_texts(texts[20:40], props[20:40], "Chunks")
+        raise AssertionError("the failing add did not surface")
+    except RuntimeError as e:
+        assert "hipMalloc" in str(e)
+    assert len(table.rows) == 20 and len(table.index) == 20
+    assert await store.query_by_keys([props[25]["documentKey"]], "ws1", "kb1", "Chunks") == []
+    await store.upsert_texts(texts[20:40], props[20:40], "Chunks")
+    res = await store.query(texts[25], "ws1", "kb1", "Chunks", topk=1, topn=1)
+    assert res and res[0]["documentKey"] == props[25]["documentKey"]
+    await store.upsert_texts(texts[40:], props[40:], "Chunks")
+    # 2. queries interleaved with deletes and compactions: no exception, no row of a deleted document, and every
+    # answer's payload belongs to the row its distance was computed for
+    async def reader(j):
+        out = []
+        for r in range(12):
+            res = await store.query(texts[(7 * j + r) % 60], "ws1", "kb1", "Chunks", topk=5, topn=5, distance_threshold=1.5)
+            for rec in res:
+                i = rec["chunkIdx"]
+                d = float(po.cosine_distance(po.round_storage(embed_text(texts[i])[None, :].astype(np.float32), storage),
+                                             po.round_storage(embed_text(texts[(7 * j + r) % 60]).astype(np.float32), storage))[0])
+                assert abs(d - rec["distance"]) < 1e-5, "payload of another row"
+            out.append(res)
+            await asyncio.sleep(0)
+        return out
+
+    async def writer():
+        for doc in ("doc-0", "doc-1"):
+            await asyncio.sleep(0)
+            assert await store.clean_table("Chunks", {"documentId": doc})
+            await store.compact("Chunks")
+
+    await asyncio.gather(writer(), *[reader(j) for j in range(6)])
+    assert all(row["documentId"] == "doc-2" for row in table.rows) and len(table.rows) == len(table.index) == 20
+    res = await store.query(texts[2], "ws1", "kb1", "Chunks", topk=3, topn=3)
+    assert res[0]["documentKey"] == props[2]["documentKey"] and all(r["documentId"] == "doc-2" for r in res)
 
 
 def run(coro):

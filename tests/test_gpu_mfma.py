@@ -396,3 +396,17 @@ def test_filter_route_on_ladders_of_close_rows(hvs):
         dist, ids, cnt = idx.search(q[s : s + 1], k=32, max_distance=thr, algo="mfma")
         assert cnt[0] == 7 and ids[0][:7].tolist() == np.argsort(dm[s], kind="stable")[:7].tolist(), f"thr on ladder {delta}"
     idx.close()
+
+
+def test_kmeans_on_an_empty_index_returns_zero_sums(hvs):
+    """A rank whose shard is empty must feed zeros into the centroid all-reduce."""
+    import torch
+
+    idx = hvs.HvsIndex(32, "f32")
+    c = np.random.default_rng(1).standard_normal((5, 32)).astype(np.float32)
+    assign, sums, counts = idx.kmeans_assign(c)
+    assert assign.shape == (0,) and not sums.any() and not counts.any()
+    ct = torch.from_numpy(c).cuda()
+    assign, sums, counts = idx.kmeans_assign(ct)
+    assert int(sums.abs().sum().item()) == 0 and int(counts.sum().item()) == 0
+    idx.close()

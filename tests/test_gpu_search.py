@@ -523,3 +523,108 @@ def test_repeated_small_searches_follow_the_table(hvs, dtype):
     idx.profile(False)
     check(rows2[keep], np.ones(int(keep.sum()), bool), "again", reps=3)
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_attribute_filters_are_evaluated_on_the_device(hvs, dtype):
+    """hvs_search_filtered / hvs_range_search_filtered: workspace-only, knowledge-base-only, uri IN (...) and private =
+    clauses over the attribute columns, alone and combined with the group code, a row range and tombstones, on the scan
+    and the batched paths; the attributes move with their rows through a compaction."""
+    rng = np.random.default_rng(2024)
+    n, d = 50_003, 96
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    ws = rng.integers(0, 5, n).astype(np.int32)
+    kb = rng.integers(0, 3, n).astype(np.int32)
+    uri = rng.integers(0, 20_000, n).astype(np.int32)
+    priv = rng.random(n) < 0.3
+    groups = (ws * 3 + kb).astype(np.int32)
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows[:30_000], group_codes=groups[:30_000])
+    idx.set_attributes(0, workspace=ws[:30_000], knowledge_base=kb[:30_000], uri=uri[:30_000], private=priv[:30_000])
+    idx.add(rows[30_000:], group_codes=groups[30_000:])  # a second batch: the attribute column grows with the table
+    idx.set_attributes(30_000, workspace=ws[30_000:], knowledge_base=kb[30_000:], uri=uri[30_000:], private=priv[30_000:])
+    dead = rng.choice(n, 500, replace=False)
+    idx.set_deleted(dead)
+    alive = np.ones(n, bool)
+    alive[dead] = False
+    q = rng.standard_normal((40, d)).astype(np.float32)
+    big_uri_list = rng.choice(20_000, 6_000, replace=False)
+    cases = [
+        ({"workspace": 2}, ws == 2),
+        ({"knowledge_base": 1}, kb == 1),
+        ({"access": True}, priv),
+        ({"access": False, "workspace": 0}, ~priv & (ws == 0)),
+        ({"uris": [7, 19_999, 123, 123]}, np.isin(uri, [7, 19_999, 123])),
+        ({"uris": big_uri_list, "knowledge_base": 2}, np.isin(uri, big_uri_list) & (kb == 2)),
+        ({"group": 7, "access": True}, (groups == 7) & priv),
+        ({"group": 4}, groups == 4),
+        ({"uris": []}, np.zeros(n, bool)),
+    ]
+    for filt, keep in cases:
+        keep = keep & alive
+        for algo, nq, k in (("scan", 3, 10), ("mfma", 40, 10), ("auto", 1, 100)):
+            dist, ids, cnt = idx.search(q[:nq], k=k, filter=filt, max_distance=1.2, algo=algo)
+            for i in range(nq if algo != "mfma" else 6):
+                parity.check_topk(dist[i], ids[i], cnt[i], parity.full_distances(rows, q[i], dtype), k, threshold=1.2, keep=keep,
+                                  label=f"{dtype} {sorted(filt)} {algo} q={i}")
+        rkeep = keep.copy()
+        rkeep[:1000] = False
+        rkeep[45_000:] = False
+        dist, ids, cnt = idx.search(q[:2], k=10, filter=filt, row_begin=1000, row_end=45_000, algo="scan")
+        parity.check_topk(dist[0], ids[0], cnt[0], parity.full_distances(rows, q[0], dtype), 10, keep=rkeep, label=f"{dtype} {sorted(filt)} range")
+        rd, ri, total = idx.range_search(q[:3], 0.9, filter=filt)
+        full = parity.full_distances(rows, q[:3], dtype)
+        with np.errstate(invalid="ignore"):
+            exp = np.flatnonzero(keep & (full < 0.9))
+        near = int((keep & (np.abs(full - 0.9) <= 1e-6)).sum())
+        assert abs(total - len(exp)) <= near and (near or ri.tolist() == exp.tolist())
+    # torch queries on the device take the same route
+    import torch
+
+    dt, it, ct = idx.search(torch.from_numpy(q[:3]).cuda(), k=10, filter={"workspace": 2}, max_distance=1.2, algo="scan")
+    dn, in_, cn = idx.search(q[:3], k=10, filter={"workspace": 2}, max_distance=1.2, algo="scan")
+    assert np.array_equal(it.cpu().numpy(), in_) and np.array_equal(dt.cpu().numpy(), dn)
+    # compaction: attributes follow their rows
+    assert idx.compact(renumber_ids=True) == n - 500
+    live_rows = rows[alive]
+    for filt, keep in cases[:6]:
+        dist, ids, cnt = idx.search(q[:2], k=10, filter=filt, algo="scan")
+        for i in range(2):
+            parity.check_topk(dist[i], ids[i], cnt[i], parity.full_distances(live_rows, q[i], dtype), 10, keep=keep[alive],
+                              label=f"{dtype} {sorted(filt)} after compaction")
+    with pytest.raises(hvs.HvsError):
+        idx.search(q[:1], k=5, filter={"uris": np.arange(9000)})  # more codes than the device's list holds
+    with pytest.raises(ValueError):
+        idx.search(q[:1], k=5, filter={"workspace": 1}, group_filter=2)
+    idx.close()
+
+
+def test_device_positions_are_range_checked(hvs):
+    """hvs_gather / hvs_index_update with positions in device memory: a position outside the table is refused before any
+    kernel uses it."""
+    import ctypes
+
+    import torch
+
+    from hirag_prod_amd import _lib
+
+    lib = hvs.load_library()
+    idx = hvs.HvsIndex(16, "f32")
+    rows = np.random.default_rng(3).standard_normal((100, 16)).astype(np.float32)
+    idx.add(rows)
+    out = torch.zeros((3, 16), device="cuda")
+    good = torch.tensor([5, 99, 0], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    _lib.check(lib.hvs_gather(idx._h, ctypes.c_void_p(good.data_ptr()), 3, ctypes.c_void_p(out.data_ptr()), 1))
+    idx.sync()
+    assert np.array_equal(out.cpu().numpy(), rows[[5, 99, 0]])
+    for bad_value in (100, -1, 1 << 40):
+        bad = torch.tensor([5, bad_value, 0], dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        assert lib.hvs_gather(idx._h, ctypes.c_void_p(bad.data_ptr()), 3, ctypes.c_void_p(out.data_ptr()), 1) != 0
+        assert b"outside" in lib.hvs_last_error()
+        new = torch.ones((3, 16), device="cuda")
+        torch.cuda.synchronize()
+        assert lib.hvs_index_update(idx._h, ctypes.c_void_p(bad.data_ptr()), ctypes.c_void_p(new.data_ptr()), _lib.HVS_F32, 3, 1) != 0
+    assert np.array_equal(idx.gather(np.arange(100)), rows)  # nothing was written
+    idx.close()

@@ -44,6 +44,28 @@ def test_store_concurrent_queries_share_launches_gpu(vector_type, storage):
     s.close()
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
+def test_store_filters_reach_the_index_as_codes_gpu(vector_type, storage):
+    s = _store(vector_type)
+    store_cases.run(store_cases.scenario_no_host_mask(s, storage))
+    s.close()
+
+
+def test_store_failed_insert_and_concurrent_delete_compact_gpu():
+    def make_add_fail(index, exc):
+        real = index.add
+
+        def add_once(*a, **kw):
+            index.add = real
+            raise exc
+
+        index.add = add_once
+
+    s = _store("halfvec")
+    store_cases.run(store_cases.scenario_failed_add_and_races(s, "f16", make_add_fail))
+    s.close()
+
+
 def test_store_many_embeddings_gpu():
     s = _store("halfvec")
     store_cases.run(store_cases.scenario_many_embeddings(s, "f16"))

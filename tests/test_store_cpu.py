@@ -33,6 +33,17 @@ def test_store_concurrent_queries_share_launches():
     store_cases.run(store_cases.scenario_concurrent_queries(_store("halfvec"), "f16"))
 
 
+def test_store_filters_reach_the_index_as_codes():
+    store_cases.run(store_cases.scenario_no_host_mask(_store("halfvec"), "f16"))
+
+
+def test_store_failed_insert_and_concurrent_delete_compact():
+    def make_add_fail(index, exc):
+        index.fail_next_add = exc
+
+    store_cases.run(store_cases.scenario_failed_add_and_races(_store("halfvec"), "f16", make_add_fail))
+
+
 def test_store_many_embeddings():
     store_cases.run(store_cases.scenario_many_embeddings(_store("halfvec"), "f16"))
 
