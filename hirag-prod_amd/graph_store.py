@@ -19,7 +19,7 @@ import math
 import time
 from datetime import datetime
 from types import SimpleNamespace
-from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -170,20 +170,21 @@ class HipGraphStore:
         graph = self._device_graph(state)
         if graph is None:
             return []
-        nodes: List[int] = []
-        weights: List[float] = []
-        total = 0.0
-        for node, w in (reset_weights or {}).items():
-            if node in state.index:
-                try:
-                    val = float(w)
-                except Exception:
-                    continue
-                if not math.isfinite(val) or val <= 0:
-                    continue
-                nodes.append(state.index[node])
+        # seeds = the reset entries that name a node of this graph and carry a finite weight > 0 (pgvector.py:414-428),
+        # normalised to sum 1; the sum runs in the mapping's order, as the reference's does
+        known = [(state.index[node], w) for node, w in (reset_weights or {}).items() if node in state.index]
+        nodes, weights = [], []
+        for slot, w in known:
+            try:
+                val = float(w)
+            except (TypeError, ValueError):
+                continue
+            if math.isfinite(val) and val > 0:
+                nodes.append(slot)
                 weights.append(val)
-                total += val
+        total = 0.0
+        for val in weights:
+            total += val
         if total <= 0:
             return []
         graph.pagerank(nodes, [w / total for w in weights], alpha=alpha)
@@ -223,6 +224,54 @@ async def apply_reranking(query, results: List[dict], topk: int, topn: int, rera
         raise ValueError(f"topn ({topn}) must be <= topk ({topk})")
     reranked = await reranker.rerank(query=query, items=results[:topk], key=key, rerank_with_time=rerank_with_time)
     return reranked[:topn]
+
+
+def reset_weights(chunk_ids: Sequence[Optional[str]], triplets: Sequence[Dict[str, Any]], chunk_counts: Dict[str, int],
+                  link_top_k: int, passage_node_weight: float) -> Tuple[Dict[str, float], Dict[str, float]]:
+    """The personalisation vector of the fusion step (what src/hirag_prod/storage/query_service.py:290-379 arrives at),
+    as arithmetic on two small arrays.  Returns ``(seeds, facts)``: ``seeds`` maps graph nodes to reset weights in the
+    order the PageRank call receives them, ``facts`` the entity part alone (empty = no fact signal).
+
+    Passages: the retrieved chunks in rank order carry ``1/rank``, moved to ``[0, passage_node_weight]`` by min-max
+    scaling (``lo = 1/m``, ``hi = 1``; a single chunk scales by 1 and so gets 0); a key that occurs twice keeps its later
+    rank.  Facts: an entity's mass is the sum of ``1/rank`` over the triplet ends that name it, added in rank order,
+    divided by the number of chunks that mention the entity (``chunk_counts``; entities it does not list, and counts
+    <= 0, divide by 1) and by the number of ends; the ``max(1, link_top_k)`` heaviest stay, ties in order of first
+    appearance.  Only weights > 0 seed the walk; a node named on both sides gets the sum.
+    """
+    ranked = [c for c in chunk_ids if c]
+    seeds: Dict[str, float] = {}
+    if ranked:
+        inv = 1.0 / np.arange(1, len(ranked) + 1, dtype=np.float64)
+        lo, hi = inv[-1], inv[0]
+        scaled = (inv - lo) / ((hi - lo) if hi > lo else 1.0) * passage_node_weight
+        final = dict(zip(ranked, scaled.tolist()))  # later duplicates overwrite
+        seeds = {c: w for c, w in final.items() if w > 0}
+
+    slot_of: Dict[str, int] = {}
+    ends: List[int] = []
+    end_rank: List[int] = []
+    for rank, rel in enumerate(triplets or ()):
+        for ent in (rel.get("source"), rel.get("target")):
+            if ent:
+                ends.append(slot_of.setdefault(ent, len(slot_of)))
+                end_rank.append(rank)
+    facts: Dict[str, float] = {}
+    if slot_of:
+        mass = np.zeros(len(slot_of), dtype=np.float64)
+        np.add.at(mass, ends, 1.0 / (np.asarray(end_rank, dtype=np.float64) + 1.0))  # unbuffered: added in rank order
+        n_ends = np.bincount(ends, minlength=len(slot_of)).astype(np.float64)
+        names = list(slot_of)
+        listed = np.fromiter((n in chunk_counts for n in names), dtype=bool, count=len(names))
+        mentions = np.fromiter((float(chunk_counts.get(n) or 0) for n in names), dtype=np.float64, count=len(names))
+        mentions[mentions <= 0] = 1.0
+        mass[listed] = (mass[listed] / mentions[listed]) / n_ends[listed]
+        keep = np.argsort(-mass, kind="stable")[: max(1, link_top_k)]
+        facts = {names[j]: float(mass[j]) for j in keep}
+        for ent, w in facts.items():
+            if w > 0:
+                seeds[ent] = seeds.get(ent, 0.0) + w
+    return seeds, facts
 
 
 class FusionQueryService:
@@ -287,53 +336,16 @@ class FusionQueryService:
         link_top_k = link_top_k or DEFAULT_LINK_TOP_K
         passage_node_weight = passage_node_weight or DEFAULT_PASSAGE_NODE_WEIGHT
         damping = damping or DEFAULT_PAGERANK_DAMPING
-        query_chunk_ids = [c.get("documentKey") for c in query_chunks if c.get("documentKey")]
         if triplet_recall is None:
             triplet_recall = await self.recall_triplets(query, workspace_id, knowledge_base_id, topk, topn)
-        query_triplets = triplet_recall["relations"]
-        query_entity_ids = triplet_recall["entity_ids"]
-
-        passage_weights: Dict[str, float] = {}
-        raw = []
-        for rank, cid in enumerate(query_chunk_ids):
-            if cid:
-                w = 1.0 / (rank + 1)
-                passage_weights[cid] = w
-                raw.append(w)
-        if raw:
-            lo, hi = min(raw), max(raw)
-            scale = (hi - lo) if (hi - lo) > 0 else 1.0
-            for cid in list(passage_weights):
-                passage_weights[cid] = ((passage_weights[cid] - lo) / scale) * passage_node_weight
-
-        phrase_weights: Dict[str, float] = {}
-        if query_triplets:
-            occurrences: Dict[str, int] = {}
-            for rank, rel in enumerate(query_triplets):
-                base = 1.0 / (rank + 1)
-                for ent in (rel.get("source"), rel.get("target")):
-                    if not ent:
-                        continue
-                    phrase_weights[ent] = phrase_weights.get(ent, 0.0) + base
-                    occurrences[ent] = occurrences.get(ent, 0) + 1
-            counts = await asyncio.gather(*[self._entity_chunk_count(e, workspace_id, knowledge_base_id) for e in query_entity_ids])
-            for ent, freq in zip(query_entity_ids, counts):
-                denom = float(freq) if freq and freq > 0 else 1.0
-                phrase_weights[ent] = (phrase_weights[ent] / denom) / float(occurrences.get(ent, 1))
-            phrase_weights = dict(sorted(phrase_weights.items(), key=lambda kv: kv[1], reverse=True)[: max(1, link_top_k)])
-
-        if not phrase_weights:
+        entities = triplet_recall["entity_ids"]
+        counts = await asyncio.gather(*[self._entity_chunk_count(e, workspace_id, knowledge_base_id) for e in entities]) if triplet_recall["relations"] else []
+        seeds, facts = reset_weights([c.get("documentKey") for c in query_chunks], triplet_recall["relations"], dict(zip(entities, counts)),
+                                     link_top_k, passage_node_weight)
+        if not facts:  # no fact signal: the retrieval order stands (query_service.py:367-368)
             return {"pagerank": [], "query_top": query_chunks}
 
-        reset_weights: Dict[str, float] = {}
-        for k, v in passage_weights.items():
-            if v > 0:
-                reset_weights[k] = reset_weights.get(k, 0.0) + v
-        for k, v in phrase_weights.items():
-            if v > 0:
-                reset_weights[k] = reset_weights.get(k, 0.0) + v
-
-        ranked = await self.gdb.pagerank_top_chunks_with_reset(reset_weights=reset_weights, topk=topk, alpha=damping,
+        ranked = await self.gdb.pagerank_top_chunks_with_reset(reset_weights=seeds, topk=topk, alpha=damping,
                                                                workspace_id=workspace_id, knowledge_base_id=knowledge_base_id)
         ids = [cid for cid, _ in ranked]
         rows = await self.vdb.query_by_keys(key_value=ids, workspace_id=workspace_id, knowledge_base_id=knowledge_base_id,

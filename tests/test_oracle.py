@@ -134,3 +134,19 @@ def test_kmeans_oracle_matches_sklearn_golden(path):
     new_c, _, counts = kmeans_oracle.update(g["x"], a, g["c0"])
     np.testing.assert_allclose(new_c, g["centers1"], atol=1e-5)
     np.testing.assert_array_equal(pgv_scan.kmeans_assign(g["x"], g["c0"]), a)
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
+    """`make -C oracle asan`: pgv_scan.c built with -fsanitize=address,undefined, walked by its self-checking driver
+    (scan over every element kind and odd sizes with exact-size allocations, the bounded heap at k = 1 .. > n, every
+    16-bit pattern through the conversions).  CPU only."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None and shutil.which("cc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "pgv_selftest ok" in out, out[-3000:]
+    assert "AddressSanitizer" not in out and "runtime error" not in out

@@ -61,3 +61,30 @@ def test_fusion_reset_weights():
     assert phrase == {} and set(reset) == {"chunk-a", "chunk-b"}
     reset, _ = pr.fusion_reset_weights(["only"], [], [], {})
     assert reset == {}  # a single chunk: min == max -> weight 0
+
+
+def test_product_reset_weights_equal_the_oracle_statement():
+    """``graph_store.reset_weights`` (array arithmetic) against the oracle's statement of query_service.py:290-379:
+    same keys in the same order, same float64 bits."""
+    import random
+
+    from hirag_prod_amd.graph_store import reset_weights
+
+    rnd = random.Random(7)
+    for case in range(300):
+        m = rnd.randrange(0, 14)
+        chunks = [f"chunk-{rnd.randrange(0, 10)}" if rnd.random() < 0.9 else None for _ in range(m)]  # duplicates and gaps
+        ents = [f"e{j}" for j in range(rnd.randrange(1, 9))]
+        triplets = [{"source": rnd.choice(ents + [None, ""]), "target": rnd.choice(ents + [None]), "description": "x"}
+                    for _ in range(rnd.randrange(0, 12))]
+        if case % 7 == 0 and chunks and triplets:
+            triplets[0]["source"] = next((c for c in chunks if c), "chunk-0")  # a node seeded from both sides
+        entity_ids = list({e for t in triplets for e in (t.get("source"), t.get("target")) if e})
+        rnd.shuffle(entity_ids)
+        counts = {e: rnd.choice([0, 0, 1, 2, 5, -1]) for e in entity_ids}
+        k = rnd.choice([1, 2, 3, 30, 0])
+        pw = rnd.choice([0.6, 0.05, 1.0])
+        exp_reset, exp_phrase = pr.fusion_reset_weights([c for c in chunks if c], triplets, entity_ids, counts, link_top_k=k, passage_node_weight=pw)
+        got_reset, got_phrase = reset_weights(chunks, triplets, counts, k, pw)
+        assert list(got_phrase.items()) == list(exp_phrase.items()), case
+        assert list(got_reset.items()) == list(exp_reset.items()), case
