@@ -78,6 +78,7 @@ struct hvs_index {
     // nothing (a table of tight clusters), the next filter_skip calls go straight to the route that scores every row in
     // full; the run of skipped calls doubles with every failure in a row (4, 8, ... 64) and ends with the first success
     int filter_skip = 0, filter_backoff = 0;
+    int km_filter_skip = 0, km_filter_backoff = 0;  // the same for the k-means assignment's filter pass (more than a quarter of the rows flagged)
 
     hvs_workspace ws[10];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
                            // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,

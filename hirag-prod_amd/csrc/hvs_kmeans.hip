@@ -11,6 +11,15 @@
 // split copies of rows and centroids (hvs_split.hip) on v_mfma_f32_32x32x16_f16 (256 x 256 tile, three
 // slab products per element), where the power-of-two scales of both operands are divided out of the
 // accumulator before the comparison.
+//
+// Default for fp32 tables from 64 centroids on: the hi slabs alone as a filter (TOP2 instantiation).  One product
+// instead of three gives every |c|^2 - 2 x.c to within a known bound (fp16 rounding of both operands: 2^-10 (1 + 2^-10)
+// |x| |c| on the dot product); each block keeps, per corpus row, the best TWO values of its centroid tile, and
+// kmeans_pick_kernel then looks at the 2 CT values of a row: a centroid whose lower bound lies above the smallest upper
+// bound cannot be the argmin.  One centroid left: that is the assignment.  Several tile-bests left: their exact
+// fp32 values decide (a few dot products from the fp32 rows).  A tile's second-best left: the tile may hide a third
+// one, the row is flagged and goes through the three products with the other flagged rows.  The assignment is the
+// exact-arithmetic argmin in every case; what varies is the time.
 #include "hvs_gemm_tile.h"
 
 struct AssignParams {
@@ -25,12 +34,18 @@ struct AssignParams {
     int64_t n;             // rows
     int ld_bytes, nks;
     int split_steps;       // 0 = plain; else k-steps per slab (the K loop runs 3 of them: hi.hi, hi.lo, lo.hi)
+    int hi_only;           // split operands, filter pass: the K loop runs over the hi slabs alone (nks = split_steps)
     int CT, S;             // centroid tiles, corpus splits
     int64_t T;             // corpus tiles
     uint64_t *best;        // [CT, n] keys
 };
 
-template <int DT, class T>
+// Largest finite sentinel whose low byte is clear: TOP2 packs a centroid's index within its tile into the low 8 bits of
+// the value's float image (truncation: 2^-15 relative, which the pick kernel adds to the bound), and an infinity with
+// index bits would read as NaN.
+#define KM_BIG_BITS 0x7F000000u
+
+template <int DT, class T, bool TOP2 = false>
 __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_kernel(AssignParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
     static_assert(T::WM == 2, "the exchange below pairs wave row 1 with wave row 0");
@@ -60,7 +75,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
     const int64_t a_row0 = (int64_t)ct * T::BM;
     for (int i = tid; i < T::BM; i += T::GT) {
         const int64_t c = a_row0 + i;
-        cn_lds[i] = c < p.K ? p.c_norm[c] : __builtin_inff();  // padding centroids never win
+        cn_lds[i] = c < p.K ? p.c_norm[c] : (TOP2 ? __uint_as_float(KM_BIG_BITS) : __builtin_inff());  // padding centroids never win
         cs_lds[i] = c < p.K && p.c_iscale ? -2.0f * p.c_iscale[c] : -2.0f;
     }
 
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 x_is[nt] = 1.0f;
-                if (p.split_steps) {
+                if (p.x_split_inv) {
                     const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
                     if (row < p.n) {
                         const float inv = p.x_inv[row];
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
             }
         }
         KOff next_off = koff_plain(ks_next);
-        if (p.split_steps) {
+        if (p.split_steps && !p.hi_only) {
             const int slab = ks_next >= 2 * p.split_steps ? 2 : (ks_next >= p.split_steps ? 1 : 0), w = ks_next - slab * p.split_steps;
             next_off.a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
             next_off.b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
@@ -116,7 +131,43 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
 
         uint64_t bestk[NT];
         const bool last = ks == p.nks - 1;
-        if (last) {
+        if (last && TOP2) {
+            static_assert(!TOP2 || T::BM <= 256, "the index within a tile is packed into 8 bits");
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                // the lane's two smallest values, index in the low byte: min + median-of-three per value
+                float b1 = __uint_as_float(KM_BIG_BITS), b2 = b1;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;
+                        const f32x4 cn = *reinterpret_cast<const f32x4 *>(cn_lds + a_loc);
+                        const f32x4 cs = *reinterpret_cast<const f32x4 *>(cs_lds + a_loc);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float v = fmaf(acc[mt][nt][4 * gq + e] * x_is[nt], cs[e], cn[e]);
+                            // bits of wm and h are added once per lane below
+                            const float pk = __uint_as_float((__float_as_uint(v) & 0xFFFFFF00u) | (uint32_t)(mt * 32 + 8 * gq + e));
+                            const float n1 = fminf(b1, pk);
+                            b2 = __builtin_amdgcn_fmed3f(b1, b2, pk);
+                            b1 = n1;
+                        }
+                    }
+                const uint32_t lb = (uint32_t)(wm * (MT * 32) + 4 * h);
+                b1 = __uint_as_float(__float_as_uint(b1) | lb);
+                b2 = __uint_as_float(__float_as_uint(b2) | lb);
+                // the other lane half holds the other centroid rows of the same corpus row
+                const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+                const float n1 = fminf(b1, o1), n2 = fminf(fmaxf(b1, o1), fminf(b2, o2));
+                bestk[nt] = ((uint64_t)__float_as_uint(n2) << 32) | __float_as_uint(n1);
+            }
+            zero_acc(acc);
+            if (wm == 1 && h == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) xch[(wn * NT + nt) * 32 + (lane & 31)] = bestk[nt];
+            }
+        } else if (last) {
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 // per lane: strict "<" over increasing centroid index keeps the lowest index on ties
@@ -159,7 +210,15 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const uint64_t o = xch[(wn * NT + nt) * 32 + (lane & 31)];
-                const uint64_t b = o < bestk[nt] ? o : bestk[nt];
+                uint64_t b;
+                if (TOP2) {  // merge two sorted pairs
+                    const float a1 = __uint_as_float((uint32_t)bestk[nt]), a2 = __uint_as_float((uint32_t)(bestk[nt] >> 32));
+                    const float o1 = __uint_as_float((uint32_t)o), o2 = __uint_as_float((uint32_t)(o >> 32));
+                    const float n1 = fminf(a1, o1), n2 = fminf(fmaxf(a1, o1), fminf(a2, o2));
+                    b = ((uint64_t)__float_as_uint(n2) << 32) | __float_as_uint(n1);
+                } else {
+                    b = o < bestk[nt] ? o : bestk[nt];
+                }
                 const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
                 if (row < p.n) p.best[(size_t)ct * p.n + row] = b;
             }
@@ -184,6 +243,138 @@ __global__ void kmeans_reduce_kernel(const uint64_t *__restrict__ best, int CT, 
         if (deleted && ((deleted[r >> 5] >> (r & 31)) & 1u)) a = -1;
         assign[r] = a;
     }
+}
+
+// ---- filter route: the rows' assignments from the best two values per (centroid tile, row) of the hi-slab pass ----
+struct PickParams {
+    const float *best;      // [CT, n, 2] packed values (index within the tile in the low byte), smaller first
+    int CT, bm;             // centroid tiles, centroids per tile
+    int64_t n;
+    const float *x_inv;     // [n] 1 / |x| of the fp32 rows (+inf for a zero row)
+    const float *rows;      // fp32 rows, pitch ld floats
+    int ld;
+    const float *c_pad;     // fp32 centroids, pitch ldc floats (pad columns zero), ldc >= ld
+    int ldc;
+    const float *c_norm;    // [K] |c|^2
+    const float *cmax;      // [1] largest |c|
+    float eps2;             // 2 * (bound of the hi-slab dot product relative to |x| |c|)
+    const uint32_t *deleted;
+    int32_t *assign;        // [n]
+    uint32_t *flag_list;    // rows that need every product: [n] positions, any order
+    uint32_t *flag_count;
+};
+
+// One wave per row.  Value j of the row (j = 2 * tile + which) sits in lane j & 63 of register j >> 6.
+template <int R> __global__ __launch_bounds__(256) void kmeans_pick_kernel(PickParams q) {
+    const int lane = threadIdx.x & 63;
+    const float cmax = *q.cmax;
+    const int nv = 2 * q.CT;
+    for (int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6); row < q.n; row += (int64_t)gridDim.x * 4) {
+        if (q.deleted && ((q.deleted[row >> 5] >> (row & 31)) & 1u)) {
+            if (lane == 0) q.assign[row] = -1;
+            continue;
+        }
+        float v[R], lo[R];
+        const float inv = q.x_inv[row];
+        const float xn = inv < __builtin_inff() ? 1.0f / inv : 0.0f;  // a zero row: every value is |c|^2 exactly
+        const float eb = q.eps2 * xn * cmax * 1.0001f;
+        float hi_min = __builtin_inff();
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const int j = e * 64 + lane;
+            v[e] = j < nv ? q.best[((size_t)(j >> 1) * q.n + row) * 2 + (j & 1)] : __builtin_nanf("");
+            const float err = eb + fabsf(v[e]) * 3.1e-5f;  // + the truncated low byte (2^-15 relative)
+            lo[e] = v[e] - err;
+            hi_min = fminf(hi_min, v[e] + err);  // fminf drops NaN
+        }
+        for (int off = 32; off > 0; off >>= 1) hi_min = fminf(hi_min, __shfl_xor(hi_min, off));
+        uint64_t m[R];
+        int count = 0;
+        bool second = false;
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            m[e] = __ballot(lo[e] <= hi_min);  // false for NaN
+            count += __popcll(m[e]);
+            second |= (m[e] & 0xAAAAAAAAAAAAAAAAull) != 0;  // odd j: a tile's second best
+        }
+        if (count == 0 || second) {  // no finite value at all, or a tile that may hide a third contender
+            if (lane == 0) {
+                q.flag_list[atomicAdd(q.flag_count, 1u)] = (uint32_t)row;  // integer: the list's order does not reach the result
+                q.assign[row] = -1;
+            }
+            continue;
+        }
+        uint64_t best_key = HVS_KEY_EMPTY;
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            uint64_t pending = m[e];
+            while (pending) {
+                const int src = __ffsll((unsigned long long)pending) - 1;
+                pending &= pending - 1;
+                const uint32_t bits = __builtin_amdgcn_readlane(__float_as_uint(v[e]), src);
+                const uint32_t c = (uint32_t)(((e * 64 + src) >> 1) * q.bm) + (bits & 0xFFu);
+                if (count == 1) {
+                    best_key = c;
+                    break;
+                }
+                // several tile-bests within the bound of each other: exact fp32 values decide
+                const float *x = q.rows + (size_t)row * q.ld, *cc = q.c_pad + (size_t)c * q.ldc;
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                for (int i = lane * 4; i < q.ld; i += 256) {  // ld is a multiple of 4, pad columns are zero on both sides
+                    const float4 a = *reinterpret_cast<const float4 *>(x + i);
+                    const float4 b = *reinterpret_cast<const float4 *>(cc + i);
+                    s0 = fmaf(a.x, b.x, s0);
+                    s1 = fmaf(a.y, b.y, s1);
+                    s2 = fmaf(a.z, b.z, s2);
+                    s3 = fmaf(a.w, b.w, s3);
+                }
+                float dot = (s0 + s1) + (s2 + s3);
+                for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+                const float val = fmaf(-2.0f, dot, q.c_norm[c]);
+                if (val == val) {
+                    const uint64_t key = hvs_make_key(hvs_ord(val), c);  // ties go to the lower centroid
+                    best_key = key < best_key ? key : best_key;
+                }
+            }
+        }
+        if (lane == 0) q.assign[row] = best_key == HVS_KEY_EMPTY ? -1 : (int32_t)(uint32_t)best_key;
+    }
+}
+
+// cmax[0] = largest |c| (one block)
+__global__ __launch_bounds__(256) void kmeans_cmax_kernel(const float *__restrict__ c_norm, int K, float *__restrict__ cmax) {
+    __shared__ float part[4];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < K; i += 256) m = fmaxf(m, c_norm[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) cmax[0] = sqrtf(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))) * 1.000001f;
+}
+
+// the flagged rows as a table of their own: split rows and both inverse norms gathered (one wave per row) ...
+__global__ __launch_bounds__(256) void kmeans_gather_kernel(const char *__restrict__ split, int pitch16, const float *__restrict__ x_inv,
+                                                            const float *__restrict__ x_split_inv, const uint32_t *__restrict__ list,
+                                                            uint32_t n_list, char *__restrict__ dst, float *__restrict__ dst_inv,
+                                                            float *__restrict__ dst_split_inv) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= n_list) return;
+    const uint32_t r = list[i];
+    const uint4 *s = reinterpret_cast<const uint4 *>(split + (size_t)r * pitch16 * 16);
+    uint4 *d = reinterpret_cast<uint4 *>(dst + (size_t)i * pitch16 * 16);
+    for (int c = lane; c < pitch16; c += 64) d[c] = s[c];
+    if (lane == 0) {
+        dst_inv[i] = x_inv[r];
+        dst_split_inv[i] = x_split_inv[r];
+    }
+}
+
+// ... and their assignments put back in their places
+__global__ void kmeans_scatter_kernel(const int32_t *__restrict__ sub, const uint32_t *__restrict__ list, uint32_t n_list,
+                                      int32_t *__restrict__ assign) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_list) assign[list[i]] = sub[i];
 }
 
 // c_pad[j][0..ld) = centroid j zero-padded; c_norm[j] = |c_j|^2.  One wave per centroid.
@@ -211,7 +402,7 @@ __global__ void fill_ones_kernel(float *dst, int n) {
     if (i < n) dst[i] = 1.0f;
 }
 
-template <int DT, class T> static int launch_assign(AssignParams &p, int64_t n, hipStream_t st) {
+template <int DT, class T, bool TOP2 = false> static int launch_assign(AssignParams &p, int64_t n, hipStream_t st) {
     p.CT = (p.K + T::BM - 1) / T::BM;
     p.T = (n + T::BN - 1) / T::BN;
     int S = ((T::GT == 256 ? 512 : 256) + p.CT - 1) / p.CT;  // fill every block slot of the chip
@@ -221,9 +412,9 @@ template <int DT, class T> static int launch_assign(AssignParams &p, int64_t n, 
     if (S < 1) S = 1;
     p.S = S;
     const size_t lds = assign_lds_bytes<T>();
-    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<DT, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<DT, T, TOP2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    kmeans_assign_kernel<DT, T><<<p.CT * S, T::GT, lds, st>>>(p);
+    kmeans_assign_kernel<DT, T, TOP2><<<p.CT * S, T::GT, lds, st>>>(p);
     HVS_HIP(hipGetLastError());
     return 0;
 }
@@ -332,13 +523,99 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     }
 
     HVS_TRY(hvs_prof_begin(idx));
-    if (!split) HVS_TRY((launch_assign<HVS_F32, Tile128>(p, n, st)));
-    else if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128>(p, n, st)));
-    else HVS_TRY((launch_assign<HVS_F16, Tile256>(p, n, st)));
-    int rg = (int)((n + 255) / 256);
-    if (rg > 256 * 8) rg = 256 * 8;
-    kmeans_reduce_kernel<<<rg, 256, 0, st>>>(p.best, p.CT, n, idx->n_deleted > 0 ? idx->deleted : nullptr, d_assign);
-    HVS_HIP(hipGetLastError());
+    // the hi slabs as a filter: best two values per (centroid tile, row) from one product, then kmeans_pick_kernel
+    bool done = false;
+    const int CT = (K + bm - 1) / bm;
+    bool filter = split && 2 * CT <= 256 && n <= (int64_t)0xFFFFFFFFll && !getenv("HVS_NO_FILTER");
+    if (filter && idx->km_filter_skip > 0 && !getenv("HVS_NO_ADAPT")) {  // recent filter passes on this table flagged too many rows
+        idx->km_filter_skip--;
+        filter = false;
+    }
+    if (filter) {
+        AssignParams p1 = p;
+        p1.hi_only = 1;
+        p1.nks = p.split_steps;
+        if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128, true>(p1, n, st)));
+        else HVS_TRY((launch_assign<HVS_F16, Tile256, true>(p1, n, st)));
+        void *fl = nullptr;
+        HVS_TRY(hvs_ws_get(idx, 2, 256 + (size_t)n * 4, &fl));
+        uint32_t *flag_count = (uint32_t *)fl, *flag_list = (uint32_t *)((char *)fl + 256);
+        float *cmax = (float *)((char *)fl + 64);
+        HVS_HIP(hipMemsetAsync(fl, 0, 256, st));
+        kmeans_cmax_kernel<<<1, 256, 0, st>>>(c_norm, K, cmax);
+        HVS_HIP(hipGetLastError());
+        PickParams q;
+        memset(&q, 0, sizeof(q));
+        q.best = (const float *)p.best;
+        q.CT = p1.CT;
+        q.bm = bm;
+        q.n = n;
+        q.x_inv = idx->inv_norm;
+        q.rows = (const float *)idx->rows;
+        q.ld = ld;
+        q.c_pad = c_pad;
+        q.ldc = ldc;
+        q.c_norm = c_norm;
+        q.cmax = cmax;
+        // |x.c - xh.ch / scales| <= (2^-10 (1 + 2^-10) + n 2^-24 [fp32 accumulation of exact products]) |x| |c|, twice that on |c|^2 - 2 x.c
+        q.eps2 = 2.0f * (9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f);
+        q.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
+        q.assign = d_assign;
+        q.flag_list = flag_list;
+        q.flag_count = flag_count;
+        int pg = (int)((n + 3) / 4);
+        if (pg > 256 * 64) pg = 256 * 64;
+        const int nv = 2 * p1.CT;
+        if (nv <= 64) kmeans_pick_kernel<1><<<pg, 256, 0, st>>>(q);
+        else if (nv <= 128) kmeans_pick_kernel<2><<<pg, 256, 0, st>>>(q);
+        else kmeans_pick_kernel<4><<<pg, 256, 0, st>>>(q);
+        HVS_HIP(hipGetLastError());
+        uint32_t n_flag = 0;
+        HVS_HIP(hipMemcpyAsync(&n_flag, flag_count, 4, hipMemcpyDeviceToHost, st));
+        HVS_HIP(hipStreamSynchronize(st));
+        idx->prof_launches[HVS_PROF_REDO] += n_flag;
+        if ((int64_t)n_flag * 4 > n) {  // a table of tight clusters: the whole table through the three products, and not this way again for a while
+            idx->km_filter_backoff = idx->km_filter_backoff == 0 ? 4 : (idx->km_filter_backoff >= 32 ? 64 : 2 * idx->km_filter_backoff);
+            idx->km_filter_skip = idx->km_filter_backoff;
+        } else {
+            idx->km_filter_backoff = 0;
+            done = true;
+            if (n_flag > 0) {  // the flagged rows as a table of their own, all three products
+                const int pitch = ld16 * 4;
+                const size_t o_inv = up((size_t)n_flag * pitch + HVS_ROWS_SLACK), o_sinv = o_inv + up((size_t)n_flag * 4),
+                             o_sub = o_sinv + up((size_t)n_flag * 4);
+                void *g = nullptr, *sub_best = nullptr;
+                HVS_TRY(hvs_ws_get(idx, 7, o_sub + up((size_t)n_flag * 4), &g));
+                HVS_TRY(hvs_ws_get(idx, 4, (size_t)CT * n_flag * 8, &sub_best));
+                HVS_HIP(hipMemsetAsync((char *)g + (size_t)n_flag * pitch, 0, HVS_ROWS_SLACK, st));
+                float *g_inv = (float *)((char *)g + o_inv), *g_sinv = (float *)((char *)g + o_sinv);
+                int32_t *sub_assign = (int32_t *)((char *)g + o_sub);
+                kmeans_gather_kernel<<<(n_flag + 3) / 4, 256, 0, st>>>((const char *)idx->split, pitch / 16, idx->inv_norm, idx->split_inv, flag_list,
+                                                                       n_flag, (char *)g, g_inv, g_sinv);
+                HVS_HIP(hipGetLastError());
+                AssignParams p3 = p;
+                p3.X = g;
+                p3.x_inv = g_inv;
+                p3.x_split_inv = g_sinv;
+                p3.n = n_flag;
+                p3.best = (uint64_t *)sub_best;
+                if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128>(p3, n_flag, st)));
+                else HVS_TRY((launch_assign<HVS_F16, Tile256>(p3, n_flag, st)));
+                kmeans_reduce_kernel<<<(n_flag + 255) / 256, 256, 0, st>>>(p3.best, p3.CT, n_flag, nullptr, sub_assign);
+                kmeans_scatter_kernel<<<(n_flag + 255) / 256, 256, 0, st>>>(sub_assign, flag_list, n_flag, d_assign);
+                HVS_HIP(hipGetLastError());
+            }
+        }
+    }
+    if (!done) {
+        if (!split) HVS_TRY((launch_assign<HVS_F32, Tile128>(p, n, st)));
+        else if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128>(p, n, st)));
+        else HVS_TRY((launch_assign<HVS_F16, Tile256>(p, n, st)));
+        int rg = (int)((n + 255) / 256);
+        if (rg > 256 * 8) rg = 256 * 8;
+        kmeans_reduce_kernel<<<rg, 256, 0, st>>>(p.best, p.CT, n, idx->n_deleted > 0 ? idx->deleted : nullptr, d_assign);
+        HVS_HIP(hipGetLastError());
+    }
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_KMEANS_ASSIGN));
 
     if (out_sums) {

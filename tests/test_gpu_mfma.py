@@ -204,13 +204,17 @@ def test_mfma_auto_dispatch_and_synthetic(hvs):
     idx.close()
 
 
-@pytest.mark.parametrize("route", ["default", "fp32"])
-@pytest.mark.parametrize("n,d,kc", [(5000, 64, 5), (3500, 72, 100), (3000, 100, 200), (4100, 1536, 300)])
+@pytest.mark.parametrize("route", ["default", "split", "fp32"])
+@pytest.mark.parametrize("n,d,kc", [(5000, 64, 5), (3500, 72, 100), (3000, 100, 200), (4100, 1536, 300), (2500, 48, 700)])
 def test_kmeans_assign_matches_oracle(hvs, n, d, kc, route, monkeypatch):
-    """From 64 centroids on the default route contracts the [hi | lo] fp16 split copies on the 16-bit
-    pipe (128-tile up to 128 centroids, 256-tile beyond); HVS_NO_SPLIT keeps the fp32 MFMA kernel."""
+    """From 64 centroids on the default route contracts the hi slabs of the [hi | lo] fp16 split copies on the 16-bit
+    pipe (128-tile up to 128 centroids, 256-tile beyond), keeps the best two values per centroid tile and row and
+    settles what their bound leaves open with exact fp32 values; HVS_NO_FILTER contracts all three slab products for
+    every row; HVS_NO_SPLIT keeps the fp32 MFMA kernel."""
     if route == "fp32":
         monkeypatch.setenv("HVS_NO_SPLIT", "1")
+    if route == "split":
+        monkeypatch.setenv("HVS_NO_FILTER", "1")
     rng = np.random.default_rng(n + kc)
     x = rng.standard_normal((n, d)).astype(np.float32)
     x[: n // 4] *= np.float32(300.0)   # rows of very different norms: every row has its own split scale
@@ -240,6 +244,49 @@ def test_kmeans_assign_matches_oracle(hvs, n, d, kc, route, monkeypatch):
     np.testing.assert_array_equal(a2, assign)
     assert s2 is None and c2 is None
     idx.close()
+
+
+def test_kmeans_filter_flags_rows_between_near_centroids(hvs):
+    """Centroids in tight bunches (several within the hi-slab bound of each other in one centroid tile): the rows near a
+    bunch cannot be settled by the best two values of the tile and go through the three products; a table where most
+    rows are like that takes the three products as a whole.  Exact either way."""
+    from hirag_prod_amd import _lib
+
+    rng = np.random.default_rng(77)
+    n, d, kc = 6000, 96, 512
+    c = rng.standard_normal((kc, d)).astype(np.float32)
+    # eight bunches of four centroids about 1e-3 apart (relative), each bunch inside one 256-centroid tile
+    for b in range(8):
+        at = 16 + 60 * b
+        c[at : at + 4] = c[at] * (1.0 + 1e-3 * rng.standard_normal((4, 1)).astype(np.float32)) + 2e-3 * rng.standard_normal((4, d)).astype(np.float32)
+    bunched = np.concatenate([np.arange(16 + 60 * b, 20 + 60 * b) for b in range(8)])
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    near = rng.choice(n, 600, replace=False)  # a tenth of the rows sit right at a bunch
+    x[near] = c[rng.choice(bunched, near.size)] + 1e-2 * rng.standard_normal((near.size, d)).astype(np.float32)
+    exp, margin = kmeans_oracle.assign(x, c)
+    xn = np.sum(x.astype(np.float64) ** 2, axis=1)
+    safe = margin > 1e-5 * xn
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(x)
+    idx.profile(True)
+    idx.profile_reset()
+    assign, _, counts = idx.kmeans_assign(c)
+    _, flagged = idx.profile_get(_lib.HVS_PROF_REDO)
+    assert near.size // 2 < flagged <= n // 4, flagged  # the rows at a bunch, not the table
+    np.testing.assert_array_equal(assign[safe], exp[safe])
+    assert int(counts.sum()) == n
+    # every row at a bunch: more than a quarter flagged -> the three products for the whole table, same answers
+    x2 = (c[rng.choice(bunched, n)] + 1e-2 * rng.standard_normal((n, d))).astype(np.float32)
+    idx2 = hvs.HvsIndex(d, "f32")
+    idx2.add(x2)
+    exp2, margin2 = kmeans_oracle.assign(x2, c)
+    safe2 = margin2 > 1e-5 * np.sum(x2.astype(np.float64) ** 2, axis=1)
+    for _ in range(2):  # the second call skips the filter pass (back-off) and must agree
+        a2, _, c2 = idx2.kmeans_assign(c)
+        np.testing.assert_array_equal(a2[safe2], exp2[safe2])
+        assert int(c2.sum()) == n
+    idx.close()
+    idx2.close()
 
 
 def test_kmeans_golden(hvs, golden_dir):

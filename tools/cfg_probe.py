@@ -31,11 +31,13 @@ def cfg4(rows=10_000_000, dim=1536, K=4096, iters=2):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / iters
     a_ms, a_n = idx.profile_get(_lib.HVS_PROF_KMEANS_ASSIGN)
+    _, flagged = idx.profile_get(_lib.HVS_PROF_REDO)
     u_ms, u_n = idx.profile_get(_lib.HVS_PROF_KMEANS_UPDATE)
     flops = 2.0 * K * rows * dim
     print(f"cfg4 kmeans rows={rows} dim={dim} K={K}: assign {a_ms / a_n:.1f} ms = {flops / (a_ms / a_n) / 1e9:.1f} TFLOP/s "
           f"({flops / (a_ms / a_n) / 1e9 / 157.3 * 100:.1f}% of the 157.3 fp32 MFMA peak; the split operands run on the 16-bit pipe), update {u_ms / u_n:.1f} ms "
-          f"({rows * dim * 4 / (u_ms / u_n) / 1e6:.0f} GB/s of added bytes), iteration wall {wall * 1e3:.1f} ms", flush=True)
+          f"({rows * dim * 4 / (u_ms / u_n) / 1e6:.0f} GB/s of added bytes), iteration wall {wall * 1e3:.1f} ms; rows sent through all three products per iteration: {flagged / max(a_n, 1):.0f} "
+          f"({flagged / max(a_n, 1) / rows * 100:.2f} %)", flush=True)
     assert int(counts.sum().item()) == rows
     idx.close()
 
