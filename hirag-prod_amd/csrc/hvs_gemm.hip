@@ -49,6 +49,8 @@ struct SearchParams {
     unsigned long long *prof;  // timing experiments only: per-phase cycle sums of wave 0 lanes (HVS_DBG & 512)
     const uint32_t *remap;  // optional: X holds a compacted copy; remap[r] = row position of its row r in the index
     float *dist_out;  // distance-column kernels: LEAST over all A rows of every corpus row, [row_end - row_begin]
+    const float *tau0;  // optional, [nq_out]: an upper bound on every query's k-th distance known before the launch (the k-th
+                        // distance over a sample of the rows); a block then starts from min(thr, tau0) instead of thr
     int split_steps;  // 0: plain operands.  > 0: both operands hold rows [hi slab | lo slab] of split_steps k-steps each
                       // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
@@ -208,14 +210,20 @@ __device__ __forceinline__ void block_coords(const SearchParams &p, int &qt, int
     }
 }
 
-template <class T> __device__ __forceinline__ void block_state_init(const SearchParams &p, const BlockState &b, int64_t a_row0, int tid) {
+template <class T> __device__ __forceinline__ void block_state_init(const SearchParams &p, const BlockState &b, int64_t a_row0, int tid, int fold) {
     for (int i = tid; i < T::BM; i += T::GT) {
-        b.tau[i] = p.thr;
+        // tau by folded query (the first BM / fold entries are used), bound and 1/|q| by A row
+        const int64_t qo = a_row0 / fold + i;
+        float t = p.thr;
+        if (p.tau0 && qo < p.nq_out) t = fminf(t, p.tau0[qo]);
+        b.tau[i] = t;
         b.cnt[i] = 0;
         const int64_t ar = a_row0 + i;
         const float qi = ar < p.nA ? p.q_inv[ar] : 0.0f;
         b.qinv[i] = qi;
-        b.bound[i] = ar < p.nA ? prefilter_bound(p.thr, qi) : INFINITY;  // padding rows of the A tile never pass
+        float tr = p.thr;
+        if (p.tau0 && ar < p.nA) tr = fminf(tr, p.tau0[ar / fold]);
+        b.bound[i] = ar < p.nA ? prefilter_bound(tr, qi) : INFINITY;  // padding rows of the A tile never pass
     }
 }
 
@@ -257,7 +265,7 @@ __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const Block
     // of the 16 bounds -- one v_max3 chain, one multiply, one compare per tile; it is used once the block has
     // seen enough rows for most tiles to hold no survivor (about k / rows_seen of the scores survive).
     // Level 2, per group of four scores (four adjacent queries): the test proper.
-    const bool level1 = (int64_t)p.k * 4096 < (tile - tile_first) * T::BN;
+    const bool level1 = p.tau0 != nullptr || (int64_t)p.k * 4096 < (tile - tile_first) * T::BN;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         f32x4 bnd[4];
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
     const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
     const int64_t a_row0 = (int64_t)qt * BM;
     const BlockState b = block_state<T>(smem, p, FOLD);
-    block_state_init<T>(p, b, a_row0, tid);
+    block_state_init<T>(p, b, a_row0, tid, FOLD);
 
     f32x16 acc[MT][NT];
     float invn2[NT];
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
     b.qinv = reinterpret_cast<float *>(b.cnt + BM);
     b.bound = b.qinv + BM;
     b.my_cand = DISTCOL ? nullptr : p.cand + (size_t)blockIdx.x * (BM / FOLD) * p.cap;
-    block_state_init<T>(p, b, 0, tid);
+    block_state_init<T>(p, b, 0, tid, FOLD);
     float *xch = b.bound + BM;  // DISTCOL with two wave rows: [WN][NT][32] minima handed from wave row 1 to wave row 0
     static_assert(!DISTCOL || (T::WM <= 2 && BN <= 256), "the exchange area holds one wave row's minima of 256 corpus rows");
 
@@ -850,6 +858,21 @@ __global__ void build_a_kernel(const float *__restrict__ src, const float *__res
     if (threadIdx.x == 0) dst_inv[row] = src_inv[q * fold + sj];
 }
 
+// tau0[q] = the smallest float above the k-th distance of a finished pass (the main pass admits strictly below its
+// bound, and the k-th row itself must pass again), or thr where the pass found fewer than k rows
+__global__ void tau_from_topk_kernel(const float *__restrict__ dist, const int32_t *__restrict__ count, int nq, int k, float thr,
+                                     float *__restrict__ tau0) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float t = thr;
+    if (count[q] >= k) {
+        const float d = dist[(size_t)q * k + k - 1];
+        const float up = d >= 0.0f ? __uint_as_float(__float_as_uint(d) + 1u) : __uint_as_float(__float_as_uint(d) - 1u);  // next float up
+        t = fminf(thr, d == 0.0f ? 1.4e-45f : up);
+    }
+    tau0[q] = t;
+}
+
 template <int DT, class T>
 static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p) {
     const size_t lds = search_lds_bytes<T>();
@@ -954,7 +977,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     void *a_ws = nullptr;
     const size_t a_bytes = ((size_t)nA * lda_bytes + 255) & ~(size_t)255;
     const size_t a_inv_bytes = ((size_t)nA * 4 + 255) & ~(size_t)255;
-    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + a_split_bytes, &a_ws));
+    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + a_split_bytes + (((size_t)nq * 4 + 255) & ~(size_t)255), &a_ws));  // + tau0 of a sample pass
     float *A_inv = (float *)((char *)a_ws + a_bytes);
     if (idx->dtype == HVS_F32)
         build_a_kernel<float><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (float *)a_ws, A_inv, fold, pf, idx->ld, lda);
@@ -1043,106 +1066,110 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const int stream_max = 128;
     bool stream = kdt != HVS_F32 && nA <= stream_max && row_end - row_begin >= 256 * 256;
     if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= stream_max && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
-    if (stream) {
-        const int bm = nA <= 32 ? 32 : (nA <= 64 ? 64 : 128);
-        const int bn = 256;
-        // split copy: up to 64 rows both query slabs ride in a stage -- (A hi, A lo | X hi) steps, then (A hi | X lo) steps;
-        // two query images of 128 rows would leave no room for a third stage, so that tile keeps the three-product order
-        const bool dual = p.split_steps != 0 && bm <= 64;
-        if (dual) p.nks = 2 * p.split_steps;
-        p.cap = CAND_MAX;
-        p.QT = 1;
-        p.T = (row_end - row_begin + bn - 1) / bn;
-        p.S = (int)(p.T < 256 ? p.T : 256);
-        p.dbg = 0;
-        const int grid = p.S;
+    // tile shape of the two-stage kernel: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
+    bool big = kdt != HVS_F32 && nA > Tile128::BM;
+    if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
+    bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
+    if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
+    const int bm = stream ? (nA <= 32 ? 32 : (nA <= 64 ? 64 : 128)) : (big ? Tile256::BM : (small ? Tile64::BM : Tile128::BM));
+    const int bn = stream ? 256 : (big ? Tile256::BN : (small ? Tile64::BN : Tile128::BN));
+    // ring kernel on the split copy: up to 64 rows both query slabs ride in a stage -- (A hi, A lo | X hi) steps, then
+    // (A hi | X lo) steps; two query images of 128 rows would leave no room for a third stage, so that tile keeps the
+    // three-product order
+    const bool dual = stream && p.split_steps != 0 && bm <= 64;
+    if (dual) p.nks = 2 * p.split_steps;
+    p.cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: the survivors of one more tile always fit
+    p.dbg = 0;
+    if (const char *e = getenv("HVS_DBG")) p.dbg = stream ? 0 : atoi(e);
+    p.QT = stream ? 1 : (nA + bm - 1) / bm;
+
+    // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
+    auto run_pass = [&](SearchParams pp, int64_t rb, int64_t re, const float *tau0, float *o_dist, int64_t *o_ids, int32_t *o_count) -> int {
+        pp.row_begin = rb;
+        pp.row_end = re;
+        pp.tau0 = tau0;
+        pp.T = (re - rb + bn - 1) / bn;
+        int S;
+        if (stream) {
+            S = (int)(pp.T < 256 ? pp.T : 256);
+        } else {
+            // splits: fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a
+            // multiple of 8 (XCD affinity) and every split non-empty
+            const int slots = big ? 256 : (small ? 1024 : 512);
+            S = (slots + pp.QT - 1) / pp.QT;
+            S = (S + 7) / 8 * 8;
+            if ((int64_t)S > pp.T) S = (int)pp.T;
+            if (S >= 8) S = S / 8 * 8;
+            if (S < 1) S = 1;
+        }
+        pp.S = S;
+        const int grid = pp.QT * S;
         void *cand = nullptr, *bufB = nullptr;
-        const size_t cand_bytes = (size_t)grid * (bm / pf) * p.cap * 8;
-        const size_t part_bytes = (size_t)nq * p.S * k * 8;
-        const int P2 = (p.S + MERGE_FAN - 1) / MERGE_FAN;
+        const size_t cand_bytes = (size_t)grid * (bm / pf) * pp.cap * 8;
+        const size_t part_bytes = (size_t)nq * S * k * 8;
+        const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
         HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
         void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
         int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
         HVS_HIP(hipMemsetAsync(overflow, 0, 64, idx->stream));
-        p.cand = (uint64_t *)cand;
-        p.partial = (uint64_t *)bufA;
-        p.overflow = overflow;
+        pp.prof = (unsigned long long *)(overflow + 4);
+        pp.cand = (uint64_t *)cand;
+        pp.partial = (uint64_t *)bufA;
+        pp.overflow = overflow;
         HVS_TRY(hvs_prof_begin(idx));
-        if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, dual, pf, grid, idx->stream, p));
-        else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, p));
+        if (stream) {
+            if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, dual, pf, grid, idx->stream, pp));
+            else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, pp));
+        } else if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, pp)));
+        else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, pp)));
+        else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, pp)));
+        else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, pp)));
+        else if (small) HVS_TRY((launch_search<HVS_BF16, Tile64>(pf, grid, idx->stream, pp)));
+        else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128>(pf, grid, idx->stream, pp)));
+        else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, pp)));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
         HVS_TRY(hvs_prof_begin(idx));
-        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, p.S, k, d_dist, d_ids, d_count, hi_only));
+        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, o_dist, o_ids, o_count, hi_only));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
         int h_overflow = 0;
         HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));
+        if (pp.dbg & 512) {
+            unsigned long long h_prof[4] = {0, 0, 0, 0};
+            HVS_HIP(hipMemcpy(h_prof, pp.prof, sizeof(h_prof), hipMemcpyDeviceToHost));
+            const double waves = (double)grid * (big ? Tile256::NW : (small ? Tile64::NW : Tile128::NW));
+            fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f\n",
+                    h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
+        }
         HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
         return 0;
-    }
-    // tile shape: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
-    bool big = kdt != HVS_F32 && nA > Tile128::BM;
-    if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
-    bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
-    if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
-    const int bm = big ? Tile256::BM : (small ? Tile64::BM : Tile128::BM), bn = big ? Tile256::BN : (small ? Tile64::BN : Tile128::BN);
-    const int cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: the survivors of one more tile always fit
-    p.cap = cap;
-    p.QT = (nA + bm - 1) / bm;
-    p.T = (row_end - row_begin + bn - 1) / bn;
-    // splits: fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a
-    // multiple of 8 (XCD affinity) and every split non-empty
-    const int slots = big ? 256 : (small ? 1024 : 512);
-    int S = (slots + p.QT - 1) / p.QT;
-    S = (S + 7) / 8 * 8;
-    if ((int64_t)S > p.T) S = (int)p.T;
-    if (S >= 8) S = S / 8 * 8;
-    if (S < 1) S = 1;
-    p.S = S;
-    p.dbg = 0;
-    if (const char *e = getenv("HVS_DBG")) p.dbg = atoi(e);
-    const int grid = p.QT * S;
-    const int groups_per_tile = bm / pf;
+    };
 
-    void *cand = nullptr, *bufA = nullptr, *bufB = nullptr;
-    const size_t cand_bytes = (size_t)grid * groups_per_tile * cap * 8;
-    const size_t part_bytes = (size_t)nq * S * k * 8;
-    const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
-    HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
-    HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
-    bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
-    int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
-    HVS_HIP(hipMemsetAsync(overflow, 0, 64, idx->stream));
-    p.prof = (unsigned long long *)(overflow + 4);
-    p.cand = (uint64_t *)cand;
-    p.partial = (uint64_t *)bufA;
-    p.overflow = overflow;
-
-    HVS_TRY(hvs_prof_begin(idx));
-    if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, p)));
-    else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, p)));
-    else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, p)));
-    else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, p)));
-    else if (small) HVS_TRY((launch_search<HVS_BF16, Tile64>(pf, grid, idx->stream, p)));
-    else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128>(pf, grid, idx->stream, p)));
-    else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, p)));
-    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
-    HVS_TRY(hvs_prof_begin(idx));
-    HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, d_dist, d_ids, d_count, hi_only));
-    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
-    int h_overflow = 0;
-    HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
-    HVS_HIP(hipStreamSynchronize(idx->stream));
-    if (p.dbg & 512) {
-        unsigned long long h_prof[4] = {0, 0, 0, 0};
-        HVS_HIP(hipMemcpy(h_prof, p.prof, sizeof(h_prof), hipMemcpyDeviceToHost));
-        const double waves = (double)grid * (big ? Tile256::NW : (small ? Tile64::NW : Tile128::NW));
-        fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f\n",
-                h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
+    // A block tightens its admission bound from the rows it has seen itself; when the table is cut into so many
+    // splits that a block's own stream is short next to k (its k-th distance then sits at the k / rows-per-block
+    // quantile for the whole launch, and most score groups take the slow path of the epilogue), a first pass over a
+    // sample of the rows -- 1/96 of them, at least 1280 k (measured optimum, flat) -- gives every query an upper bound on its k-th distance
+    // that all blocks start from.  Any subset of the rows gives a valid bound; the sample's rows are scored again
+    // by the main pass.
+    const int64_t n_rows = row_end - row_begin;
+    const int slots_main = stream ? 256 : (big ? 256 : (small ? 1024 : 512));
+    const int64_t rows_per_block = n_rows / ((slots_main + p.QT - 1) / p.QT);
+    bool prepass = (int64_t)k * 8192 > rows_per_block && n_rows >= 262144 && (!stream || k >= 64);
+    if (const char *e = getenv("HVS_PREPASS")) prepass = atoi(e) != 0 && n_rows >= 4 * bn;
+    const float *tau0 = nullptr;
+    if (prepass) {
+        int64_t n_s = n_rows / 96 > (int64_t)k * 1280 ? n_rows / 96 : (int64_t)k * 1280;
+        if (n_s > n_rows / 4) n_s = n_rows / 4;
+        if (const char *e = getenv("HVS_PREPASS_ROWS")) n_s = atoll(e) < n_rows ? atoll(e) : n_rows;
+        n_s = (n_s + bn - 1) / bn * bn;
+        HVS_TRY(run_pass(p, row_begin, row_begin + n_s, nullptr, d_dist, d_ids, d_count));
+        float *t0 = (float *)((char *)a_ws + a_bytes + a_inv_bytes + a_split_bytes);
+        tau_from_topk_kernel<<<(nq + 255) / 256, 256, 0, idx->stream>>>(d_dist, d_count, nq, k, thr, t0);
+        HVS_HIP(hipGetLastError());
+        tau0 = t0;
     }
-    HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
-    return 0;
+    return run_pass(p, row_begin, row_end, tau0, d_dist, d_ids, d_count);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ FIXED = [  # (dim, rows, query groups, fold, k)
     (1, 300, 5, 1, 3), (3, 70, 2, 2, 10), (63, 1000, 33, 1, 10), (64, 129, 65, 1, 7), (65, 2049, 9, 3, 20),
     (127, 31, 40, 1, 40), (129, 5000, 17, 4, 128), (200, 4097, 129, 1, 1), (777, 2500, 6, 2, 50),
     (96, 3000, 256, 1, 10), (130, 700, 100, 2, 100), (50, 260, 60, 3, 128),  # 129 - 256 A rows
+    (40, 1500, 300, 1, 10), (72, 900, 128, 4, 16),  # two query tiles of 256 A rows
 ]
 
 
@@ -37,11 +38,13 @@ def _cases():
     return out
 
 
-@pytest.mark.parametrize("stream", ["auto", "ring"])
+@pytest.mark.parametrize("stream", ["auto", "ring", "sample"])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_random_shapes_all_routes(hvs, dtype, stream, monkeypatch):
     if stream == "ring":  # up to 128 A rows: the single-query-tile ring kernel, whatever the row count
         monkeypatch.setenv("HVS_STREAM", "1")
+    if stream == "sample":  # every batched search starts from the k-th distances of a pass over a sample of the rows
+        monkeypatch.setenv("HVS_PREPASS", "1")
     rng = np.random.default_rng(7)
     for dim, n, nq, fold, k in _cases():
         rows = rng.standard_normal((n, dim)).astype(np.float32)
