@@ -53,6 +53,7 @@ struct SearchParams {
                         // distance over a sample of the rows); a block then starts from min(thr, tau0) instead of thr
     int split_steps;  // 0: plain operands.  > 0: both operands hold rows [hi slab | lo slab] of split_steps k-steps each
                       // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
+    unsigned int *lockstep;  // optional: one arrival counter per (XCD, corpus split) -- see lockstep_arrive; zeroed before the launch
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
                     // 512 per-phase cycle counts printed to stderr
 };
@@ -196,7 +197,8 @@ struct BlockState {
 // a rectangle of (QT / gq) query tiles x (S / gs) splits, gq = gcd(QT, 8), gs = 8 / gq, with as few
 // query tiles as possible: their A slabs (re-read for every corpus tile) then stay in that XCD's L2,
 // and only the corpus stream comes from HBM.
-__device__ __forceinline__ void block_coords(const SearchParams &p, int &qt, int &s) {
+// Returns the number of blocks that share this block's XCD and corpus split (0: no XCD-aware mapping).
+__device__ __forceinline__ int block_coords(const SearchParams &p, int &qt, int &s) {
     if ((p.S & 7) == 0) {
         const int gq = (p.QT & 7) == 0 ? 8 : ((p.QT & 3) == 0 ? 4 : ((p.QT & 1) == 0 ? 2 : 1));
         const int gs = 8 / gq;
@@ -204,10 +206,11 @@ __device__ __forceinline__ void block_coords(const SearchParams &p, int &qt, int
         const int qn = p.QT / gq, sn = p.S / gs;
         qt = (xcd % gq) * qn + t % qn;
         s = (xcd / gq) * sn + t / qn;
-    } else {
-        qt = blockIdx.x % p.QT;
-        s = blockIdx.x / p.QT;
+        return qn;
     }
+    qt = blockIdx.x % p.QT;
+    s = blockIdx.x / p.QT;
+    return 0;
 }
 
 template <class T> __device__ __forceinline__ void block_state_init(const SearchParams &p, const BlockState &b, int64_t a_row0, int tid, int fold) {
@@ -409,7 +412,9 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / T::WN, wn = wave % T::WN;
     int qt, s;
-    block_coords(p, qt, s);
+    const int members = block_coords(p, qt, s);
+    bool in_step = p.lockstep != nullptr && members > 1;
+    unsigned int *step_counter = p.lockstep + ((blockIdx.x & 7) * p.S + s);
     const int64_t tile_lo = p.T * s / p.S, tile_hi = p.T * (s + 1) / p.S;
     const int64_t a_row0 = (int64_t)qt * BM;
     const BlockState b = block_state<T>(smem, p, FOLD);
@@ -448,6 +453,8 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
         if (nks_next == 0 && g + 1 < total_steps) init_b(ntile);
         if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
+        if (ks == 0 && tid == 0 && p.lockstep != nullptr && members > 1)
+            lockstep_arrive(step_counter, (unsigned int)(tile - tile_lo + 1), members, in_step);
         KOff next_off = koff_plain(nks_next);
         if (p.split_steps) {  // slab pairs (A, X) of the three products: (hi, hi), (hi, lo), (lo, hi)
             const int slab = nks_next >= 2 * p.split_steps ? 2 : (nks_next >= p.split_steps ? 1 : 0), w = nks_next - slab * p.split_steps;
@@ -1108,12 +1115,16 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         const size_t cand_bytes = (size_t)grid * (bm / pf) * pp.cap * 8;
         const size_t part_bytes = (size_t)nq * S * k * 8;
         const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
+        // arrival counters of lockstep_arrive: when the grid fits the chip at once (it is sized to) and blocks share streams
+        const bool lockstep = !stream && (S & 7) == 0 && !getenv("HVS_NO_LOCKSTEP");
+        const size_t ls_bytes = lockstep ? (size_t)8 * S * 4 : 0;
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
-        HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512, &bufB));
+        HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512 + ls_bytes, &bufB));
         void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
         int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
-        HVS_HIP(hipMemsetAsync(overflow, 0, 64, idx->stream));
+        HVS_HIP(hipMemsetAsync(overflow, 0, 64 + ls_bytes, idx->stream));
         pp.prof = (unsigned long long *)(overflow + 4);
+        pp.lockstep = lockstep ? (unsigned int *)(overflow + 16) : nullptr;
         pp.cand = (uint64_t *)cand;
         pp.partial = (uint64_t *)bufA;
         pp.overflow = overflow;

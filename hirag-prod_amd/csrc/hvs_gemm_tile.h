@@ -200,6 +200,24 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
     }
 }
 
+// Blocks that read the same corpus stream through one XCD's L2 start every corpus tile together: left alone they drift
+// apart by more tiles than the L2 holds, and every one of them then fetches the stream from the fabric for itself
+// (fp32 search, 4096 queries x 2M rows: 528 GB per launch without this, 166 GB with it, and 2.8 % less time).
+// One arrival counter per group in global memory (zeroed before the launch); thread 0 of a block adds one at a tile's
+// start and waits until all `members` blocks have started that tile.  The wait is bounded -- a group whose blocks are
+// not all resident (a grid larger than the chip, another kernel holding CUs) must not hang -- and a block that ever
+// runs into the bound stops waiting for good (it still counts itself in, so that the others are not held up by it).
+__device__ __forceinline__ void lockstep_arrive(unsigned int *counter, unsigned int tiles_started, int members, bool &enabled) {
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!enabled) return;
+    const unsigned int want = tiles_started * (unsigned int)members;
+    for (int spin = 0; spin < 4096; spin++) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    enabled = false;
+}
+
 template <int MT, int NT> __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)

@@ -38,6 +38,7 @@ struct AssignParams {
     int CT, S;             // centroid tiles, corpus splits
     int64_t T;             // corpus tiles
     uint64_t *best;        // [CT, n] keys
+    unsigned int *lockstep; // optional: one arrival counter per corpus split (its CT blocks share an XCD); see lockstep_arrive
 };
 
 // Largest finite sentinel whose low byte is clear: TOP2 packs a centroid's index within its tile into the low 8 bits of
@@ -63,10 +64,12 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
     const int h = lane >> 5;
 
     int ct, s;
+    bool in_step = false;
     if ((p.S & 7) == 0) {
         const int xcd = blockIdx.x & 7, t = blockIdx.x >> 3;
         ct = t % p.CT;
         s = xcd + 8 * (t / p.CT);
+        in_step = p.lockstep != nullptr && p.CT > 1;
     } else {
         ct = blockIdx.x % p.CT;
         s = blockIdx.x / p.CT;
@@ -107,6 +110,8 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
         int64_t ntile = tile;
         if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
         if (ks_next == 0 && g + 1 < total_steps) init_b(ntile);  // after the last step: re-fetch this tile's step 0 (unused)
+        if (ks == 0 && tid == 0 && (p.S & 7) == 0 && p.lockstep != nullptr && p.CT > 1)
+            lockstep_arrive(p.lockstep + s, (unsigned int)(tile - tile_lo + 1), p.CT, in_step);
         if (ks == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
@@ -411,6 +416,8 @@ template <int DT, class T, bool TOP2 = false> static int launch_assign(AssignPar
     if (S >= 8) S = S / 8 * 8;
     if (S < 1) S = 1;
     p.S = S;
+    if (p.lockstep) HVS_HIP(hipMemsetAsync(p.lockstep, 0, 4096 * 4, st));
+    if ((S & 7) != 0 || S > 4096) p.lockstep = nullptr;
     const size_t lds = assign_lds_bytes<T>();
     HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<DT, T, TOP2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
@@ -462,8 +469,9 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     const size_t ones_off = cis_off + (split ? up((size_t)K * 4) : 0);
     const size_t raw_off = ones_off + (split ? up((size_t)K * 4) : 0);
     const size_t raw_bytes = on_device ? 0 : (size_t)K * dim * 4;
+    const size_t ls_off = up(raw_off + raw_bytes);
     void *ws0 = nullptr;
-    HVS_TRY(hvs_ws_get(idx, 0, raw_off + raw_bytes, &ws0));
+    HVS_TRY(hvs_ws_get(idx, 0, ls_off + 4096 * 4, &ws0));
     const float *src = centroids;
     if (!on_device) {
         HVS_HIP(hipMemcpyAsync((char *)ws0 + raw_off, centroids, raw_bytes, hipMemcpyHostToDevice, st));
@@ -479,6 +487,7 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     p.c_norm = c_norm;
     p.K = K;
     p.n = n;
+    p.lockstep = getenv("HVS_NO_LOCKSTEP") ? nullptr : (unsigned int *)((char *)ws0 + ls_off);
     if (split) {
         float *c_is = (float *)((char *)ws0 + cis_off), *ones = (float *)((char *)ws0 + ones_off);
         fill_ones_kernel<<<(K + 255) / 256, 256, 0, st>>>(ones, K);
