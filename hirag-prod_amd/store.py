@@ -11,8 +11,10 @@ takes no part in the arithmetic.
 The graph tables and the personalised PageRank over them (``upsert_graph``, ``query_node``,
 ``pagerank_top_chunks_with_reset``, ``clean_table`` on Graph / Nodes) are served by a ``HipGraphStore``
 (``graph_store.py``) this store owns, unless it was created with ``delegate=<PGVector instance>``, which
-then receives those calls.  What is NOT here: SQLAlchemy-expression arguments of ``query_by_keys`` and
-``upsert_file_from_metadata`` (delegate or ``NotImplementedError``).
+then receives those calls.  The extra arguments of ``query_by_keys`` (``additional_data_to_select``,
+``additional_where_clause_list``, ``order_by``) are served in the plain forms of ``select_expr.py`` (the LEAST distance
+column on the GPU, predicates and sort keys over the host rows); SQLAlchemy expression objects, which only a SQL
+database can evaluate, go to the delegate or raise ``NotImplementedError``.
 """
 
 from __future__ import annotations
@@ -26,6 +28,7 @@ from typing import Any, Callable, Dict, List, Literal, Optional, Union
 
 import numpy as np
 
+from . import select_expr
 from .vdb_interface import (
     DEFAULT_DISTANCE_THRESHOLD,
     DEFAULT_QUERY_TOP_K,
@@ -653,12 +656,19 @@ class HipVectorStore(BaseVDB):
     ) -> List[dict]:
         """Rows by key (pgvector.py:606-660).  Selecting ``"vector"`` returns the stored embedding
         (widened to float) as a ``StoredVector``."""
-        if additional_data_to_select is not None or additional_where_clause_list is not None or order_by is not None:
+        extras = additional_data_to_select is not None or additional_where_clause_list is not None or order_by is not None
+        if extras and not select_expr.is_native(additional_data_to_select, additional_where_clause_list, order_by):
             if self.delegate is not None:
                 return await self.delegate.query_by_keys(
                     key_value, workspace_id, knowledge_base_id, table_name, key_column, columns_to_select,
                     additional_data_to_select, additional_where_clause_list, order_by, limit)
-            raise NotImplementedError("SQL-expression arguments of query_by_keys need a delegate store")
+            raise NotImplementedError(
+                "query_by_keys: SQL expression objects need a delegate store; this store evaluates the forms of "
+                "hirag_prod_amd.select_expr (LeastCosineDistance, row predicates, Key / Desc / column names)")
+        if extras:
+            return await self._query_by_keys_with_expressions(
+                key_value, workspace_id, knowledge_base_id, table_name, key_column, columns_to_select,
+                additional_data_to_select or {}, additional_where_clause_list, order_by, limit)
         table = self.get_model(table_name)
         if key_column not in table.colset:
             raise AttributeError(f"table {table_name} has no column {key_column!r}")
@@ -696,6 +706,89 @@ class HipVectorStore(BaseVDB):
                     rec[col] = row.get(col)
             out.append(rec)
         return out
+
+    async def _query_by_keys_with_expressions(self, key_value, workspace_id, knowledge_base_id, table_name, key_column,
+                                              columns_to_select, extra_columns, where, order_by, limit) -> List[dict]:
+        """``query_by_keys`` with extra selected columns, extra predicates and an ordering (pgvector.py:620-660: the
+        statement gains select entities, ``.where``, ``.order_by`` and ``.limit`` in that order).  A
+        ``LeastCosineDistance`` column is one pass of the distance-column kernel over the table
+        (``search_service.py:100-113``); predicates and sort keys see the metadata row."""
+        table = self.get_model(table_name)
+        if key_column not in table.colset:
+            raise AttributeError(f"table {table_name} has no column {key_column!r}")
+        if columns_to_select is None:
+            columns_to_select = [c for c in table.columns if c != "vector"]
+        clauses = [] if where is None else (list(where) if isinstance(where, (list, tuple)) else [where])
+        wanted = set(key_value) if key_value else None
+        use_ws = bool(workspace_id) and "workspaceId" in table.colset
+        use_kb = bool(knowledge_base_id) and "knowledgeBaseId" in table.colset
+        while True:
+            while table.epoch & 1:
+                await asyncio.sleep(0.001)
+            epoch = table.epoch
+            candidates = table.positions_where(key_column, wanted) if wanted is not None else None
+            hits: List[int] = []
+            for pos in (candidates if candidates is not None else range(len(table.rows))):
+                row = table.rows[pos]
+                if row is None:
+                    continue
+                if wanted is not None and row.get(key_column) not in wanted:
+                    continue
+                if use_ws and row.get("workspaceId") != workspace_id:
+                    continue
+                if use_kb and row.get("knowledgeBaseId") != knowledge_base_id:
+                    continue
+                if any(not clause(row) for clause in clauses):
+                    continue
+                hits.append(pos)
+            if order_by is not None:
+                hits = select_expr.sort_rows(order_by, table.rows, hits)
+            if limit is not None:
+                hits = hits[:limit]
+            computed: Dict[str, Any] = {}
+            for name, expr in extra_columns.items():
+                if isinstance(expr, select_expr.LeastCosineDistance):
+                    col = None
+                    if table.has_vector and table.index is not None and hits:
+                        q = expr.embeddings
+                        for s in range(0, q.shape[0], _MAX_DIST_FOLD):
+                            part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_DIST_FOLD])
+                            col = part if col is None else np.fmin(col, part)  # fmin: NaN only if both are NaN
+                    computed[name] = col
+            if table.epoch == epoch:
+                break
+        vecs = None
+        if "vector" in columns_to_select and table.has_vector and hits and table.index is not None:
+            vecs = await asyncio.to_thread(table.index.gather, np.asarray(hits, dtype=np.int64))
+        out: List[dict] = []
+        for j, pos in enumerate(hits):
+            row = table.rows[pos]
+            if row is None:  # deleted since the selection
+                continue
+            rec = {}
+            for col in columns_to_select:
+                if col == "vector" and table.has_vector:
+                    rec[col] = StoredVector(vecs[j].tolist()) if vecs is not None else None
+                elif col in table.colset:
+                    rec[col] = row.get(col)
+            for name, expr in extra_columns.items():
+                if isinstance(expr, select_expr.LeastCosineDistance):
+                    d = float(computed[name][pos]) if computed[name] is not None else float("nan")
+                    rec[name] = None if math.isnan(d) else d
+                else:
+                    rec[name] = expr(row)
+            out.append(rec)
+        return out
+
+    async def upsert_file_from_metadata(self, metadata: dict, table_name: str = "Files", mode: str = "append", **kwargs):
+        """A Files row from a metadata dict plus keyword columns, then ``upsert_file`` (pgvector.py:505-518; the
+        reference builds the row with a ``create_object`` helper its class does not define, so its own call raises --
+        here the row is the dict itself, restricted to the table's columns by ``upsert_file``)."""
+        if self.delegate is not None and table_name not in self.tables:
+            return await self.delegate.upsert_file_from_metadata(metadata, table_name, mode, **kwargs)
+        row = dict(metadata or {})
+        row.update(kwargs)
+        return await self.upsert_file(row, table_name, mode)
 
     async def get_existing_document_keys(self, uri: str, workspace_id: str, knowledge_base_id: str, table_name: str) -> List[str]:
         """``documentKey`` of every row with this uri / workspace / knowledge base (pgvector.py:662-683)."""
@@ -940,13 +1033,6 @@ class HipVectorStore(BaseVDB):
         if name in ("upsert_graph", "query_node", "pagerank_top_chunks_with_reset"):
             delegate = self.__dict__.get("delegate")
             return getattr(delegate if delegate is not None else self.graph_store, name)
-        if name == "upsert_file_from_metadata":
-            delegate = self.__dict__.get("delegate")
-            if delegate is not None:
-                return getattr(delegate, name)
-            raise NotImplementedError(
-                f"{name} is not part of this store; create it with delegate=<PGVector instance> to forward such calls"
-            )
         raise AttributeError(name)
 
     async def health_check(self) -> Dict[str, Any]:

@@ -171,12 +171,48 @@ async def scenario_basic(store, storage):
     assert "junk" not in row
     assert await store.clean_table("Files", {"documentKey": "file-1"}) is True
     assert await store.clean_table("Graph", {"documentId": "x"}) is False
+    row = await store.upsert_file_from_metadata({"documentKey": "file-2", "knowledgeBaseId": "kb1", "workspaceId": "ws1", "junk": 2},
+                                                fileName="b.pdf", uri="s3://bucket/b.pdf")
+    assert row["fileName"] == "b.pdf" and "junk" not in row
+    assert [r["documentKey"] for r in await store.query_by_keys(["file-2"], "ws1", "kb1", "Files")] == ["file-2"]
+
+    # query_by_keys with an extra selected column, an extra predicate, an ordering and a limit: the call of
+    # cross-language search (search_service.py:100-131) in this store's plain forms, paged by keyset as it pages
+    from hirag_prod_amd.select_expr import Desc, Key, LeastCosineDistance, after_cursor
+
+    e = [embed_text("text ws2 kb1 4"), embed_text("text ws2 kb1 8")]
+    order = ["fileName", Desc("chunkIdx"), Key(lambda r: r["documentKey"])]
+    live = [pr for pr in props if pr["workspaceId"] == "ws2"]  # nothing of ws2 was deleted above
+    want = sorted(live, key=lambda r: (r["fileName"], -r["chunkIdx"]))
+    pages, cursor = [], None
+    while True:
+        page = await store.query_by_keys([], "ws2", "kb1", "Chunks", columns_to_select=["documentKey", "fileName", "chunkIdx"],
+                                         additional_data_to_select={"search_sentence_cosine_distance": LeastCosineDistance(e),
+                                                                    "twice": lambda r: 2 * r["chunkIdx"]},
+                                         additional_where_clause_list=cursor, order_by=order, limit=16)
+        if not page:
+            break
+        pages.extend(page)
+        cursor = after_cursor(order, page[-1])
+    assert [r["documentKey"] for r in pages] == [r["documentKey"] for r in want]
+    assert all(r["twice"] == 2 * r["chunkIdx"] for r in pages)
+    for r in pages:  # the same column query_distance_column returns (None where the row embeds to zeros)
+        d = by_key[r["documentKey"]]
+        assert (r["search_sentence_cosine_distance"] is None) == (d is None)
+        assert d is None or abs(r["search_sentence_cosine_distance"] - d) < 1e-6
+    some = await store.query_by_keys([props[4]["documentKey"], props[8]["documentKey"], props[10]["documentKey"]], "ws2", "kb1", "Chunks",
+                                     additional_where_clause_list=[lambda r: r["chunkIdx"] != 10], order_by=[("chunkIdx", "desc")])
+    assert [r["chunkIdx"] for r in some] == [8, 4]
+
+    class SqlExpression:  # stands for a SQLAlchemy object: only a SQL database can evaluate it
+        pass
+
     try:
-        store.upsert_file_from_metadata
+        await store.query_by_keys([], "ws2", "kb1", "Chunks", order_by=[SqlExpression()])
     except NotImplementedError:
         pass
     else:
-        raise AssertionError("calls this store does not serve must not be silently accepted")
+        raise AssertionError("expressions this store cannot evaluate must not be silently accepted")
 
 
 class Rel:
