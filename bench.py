@@ -47,6 +47,7 @@ SEED_QUERY = 4321
 FP32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak of MI355X
 F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 matrix peak
 HBM_PEAK_GBS = 8000.0
+VENDOR_GEMM_F16_TFLOPS = 1190.0  # what the vendor GEMM (hipBLASLt behind torch.matmul) sustains on this chip at 4096 x 262144 x 1536 fp16, product written out, nothing selected
 
 
 def cpu_baseline(n_threads: int, rows: np.ndarray):
@@ -128,9 +129,10 @@ def timed_calls(torch, fn, iters, warm=3):
     return out
 
 
-def kernel_ms(idx, which, fn, torch, iters, warm=2):
+def kernel_ms(idx, which, fn, torch, iters, warm=2, per_call=False):
     """per-launch device time of kernel classes (HIP events on the index's stream), one sample per call of fn();
-    `which`: one counter -> list of ms, or a tuple of counters -> one list per counter"""
+    `which`: one counter -> list of ms, or a tuple of counters -> one list per counter; per_call: the sum over the
+    launches of one call instead of their mean (a search that starts with a pass over a sample launches twice)"""
     many = isinstance(which, tuple)
     counters = which if many else (which,)
     for _ in range(warm):
@@ -142,7 +144,7 @@ def kernel_ms(idx, which, fn, torch, iters, warm=2):
         fn()
         for o, w in zip(out, counters):
             ms, n = idx.profile_get(w)
-            o.append(ms / max(n, 1))
+            o.append(ms if per_call else ms / max(n, 1))
     idx.profile(False)
     return out if many else out[0]
 
@@ -197,21 +199,26 @@ def leg_cfg4(idx, hvs, _lib, torch, dev, rows):
     c = torch.from_numpy(idx.gather(np.arange(K))).to(dev)
     out = {"workload": f"{rows} x {DIM} fp32 rows, K = {K}, one Lloyd iteration (assign + partial sums + centroid division)"}
     flops = 2.0 * K * rows * DIM
-    for label, env in (("split_f16x3", None), ("fp32_mfma", "HVS_NO_SPLIT")):
+    # the library's default: hi slabs as a filter (one product, best two values per centroid tile and row), exact fp32
+    # values where the bound leaves several centroids open, all three products for the rows it cannot settle;
+    # then all three products for every row; then the fp32 MFMA kernel
+    for label, env in (("filter_f16_exact_fp32", None), ("split_f16x3", "HVS_NO_FILTER"), ("fp32_mfma", "HVS_NO_SPLIT")):
         if env:
             os.environ[env] = "1"
         try:
             def it():
                 assign, sums, counts = idx.kmeans_assign(c)
                 torch.where((counts > 0).unsqueeze(1), sums / counts.clamp(min=1).unsqueeze(1).float(), c)
-            iters = 5 if env is None else 3
+            iters = 3 if env == "HVS_NO_SPLIT" else 5
             wall = stats_ms(timed_calls(torch, it, iters, warm=1))
+            idx.profile_reset()
             a, u = (stats_ms(v) for v in kernel_ms(idx, (_lib.HVS_PROF_KMEANS_ASSIGN, _lib.HVS_PROF_KMEANS_UPDATE), it, torch, iters, warm=0))
+            flagged = idx.profile_get(_lib.HVS_PROF_REDO)[1]  # of the last iteration (the counters are reset per call)
         finally:
             if env:
                 del os.environ[env]
-        peak = FP32_MFMA_PEAK_TFLOPS if env else F16_MFMA_PEAK_TFLOPS
-        executed = flops * (1.0 if env else 3.0)
+        peak = FP32_MFMA_PEAK_TFLOPS if env == "HVS_NO_SPLIT" else F16_MFMA_PEAK_TFLOPS
+        executed = flops * (1.0 if env == "HVS_NO_SPLIT" else (3.0 if env else 1.0 + 3.0 * flagged / rows))
         out[label] = {
             "iteration": wall,
             "assign_kernel": a,
@@ -222,6 +229,9 @@ def leg_cfg4(idx, hvs, _lib, torch, dev, rows):
             "update_pass": u,
             "update_GBps": rows * DIM * 4 / (u["median_ms"] * 1e-3) / 1e9,
         }
+        if env is None:
+            out[label]["rows_sent_through_all_three_products"] = int(flagged)
+            out[label]["rows_sent_through_all_three_products_frac"] = flagged / rows
     return out
 
 
@@ -245,7 +255,7 @@ def leg_cfg5(hvs, _lib, torch, dev):
             idx.search(qq, k=k, algo=algo, **kw)
 
         wall = stats_ms(timed_calls(torch, f, 20))
-        kern = stats_ms(kernel_ms(idx, which, f, torch, 20))
+        kern = stats_ms(kernel_ms(idx, which, f, torch, 20, per_call=True))  # all launches of one call (sample pass + main pass)
         live = n // 64 if kw else n
         hbm_floor = live * d * 2 / (HBM_PEAK_GBS * 1e9) * 1e3
         mfma_floor = 2.0 * nq * live * d / (F16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
@@ -253,6 +263,7 @@ def leg_cfg5(hvs, _lib, torch, dev):
             "call": wall, "qps": nq * 1e3 / wall["median_ms"], "kernel": kern,
             "live_rows": live, "hbm_floor_ms": hbm_floor, "mfma_floor_ms": mfma_floor,
             "kernel_over_floor": kern["median_ms"] / max(hbm_floor, mfma_floor),
+            "mfma_floor_at_vendor_gemm_rate_ms": 2.0 * nq * live * d / (VENDOR_GEMM_F16_TFLOPS * 1e12) * 1e3,
             "kernel_GBps_of_live_bytes": live * d * 2 / (kern["median_ms"] * 1e-3) / 1e9,
             "kernel_TFLOPs": 2.0 * nq * live * d / (kern["median_ms"] * 1e-3) / 1e12,
         }
@@ -295,7 +306,7 @@ def leg_clustered(hvs, _lib, torch, dev, batch):
 def measured_traffic(rows_per_gpu, batch):
     """HBM-side bytes per launch of the search kernel from the committed counter passes (rocprofv3
     cannot be driven from inside this process); None when they were taken at another size."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
     try:
         with open(path) as fh:
             t = json.load(fh)["mfma_search_kernel"]
@@ -303,7 +314,7 @@ def measured_traffic(rows_per_gpu, batch):
         return None, None
     if t["rows_per_gpu"] != rows_per_gpu or t["batch"] != batch or t["dim"] != DIM:
         return None, None
-    return t["bytes"], "profiles/r1_traffic.json: " + t["how"]
+    return t["bytes"], "profiles/r2_traffic.json: " + t["how"]
 
 
 def main():
