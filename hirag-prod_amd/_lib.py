@@ -93,6 +93,7 @@ SIGNATURES = {
     "hvs_index_deleted_count": (c_int, [c_void_p, POINTER(c_int64)]),
     "hvs_index_compact": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "hvs_index_prepare": (c_int, [c_void_p, POINTER(c_int)]),
+    "hvs_index_search_copy": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "hvs_index_export": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hvs_range_search": (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int32, c_void_p, c_double, c_int64, c_int64, c_int64, c_void_p,
                                  c_void_p, POINTER(c_int64), c_int]),

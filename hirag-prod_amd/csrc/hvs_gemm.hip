@@ -136,6 +136,7 @@ __device__ __forceinline__ uint64_t cand_reduce(uint64_t *arr, int cnt, int k, i
     if (cnt <= 64) return cand_reduce_r<1>(arr, cnt, k, lane);
     if (cnt <= 128) return cand_reduce_r<2>(arr, cnt, k, lane);
     if (cnt <= 256) return cand_reduce_r<4>(arr, cnt, k, lane);
+    if (cnt <= CAND_SMALL) return cand_reduce_r<CAND_SMALL / 64>(arr, cnt, k, lane);
     return cand_reduce_r<CAND_MAX / 64>(arr, cnt, k, lane);
 }
 
@@ -358,9 +359,9 @@ __device__ __forceinline__ void compact_lists(const SearchParams &p, const Block
     }
 }
 
-// Every folded query's best k, ascending, padded, to partial[query][split][k].
-template <int FOLD, class T>
-__device__ __forceinline__ void publish_lists(const SearchParams &p, const BlockState &b, int q_out0, int s, int wave, int lane) {
+// Every folded query's best k, ascending, padded, to partial[query][split][k].  KL = registers per lane of the sort (64 KL >= k).
+template <int FOLD, class T, int KL>
+__device__ __forceinline__ void publish_lists_kl(const SearchParams &p, const BlockState &b, int q_out0, int s, int wave, int lane) {
     constexpr int groups_per_tile = T::BM / FOLD;
     for (int ql = wave; ql < groups_per_tile; ql += T::NW) {
         const int qo = q_out0 + ql;
@@ -373,7 +374,6 @@ __device__ __forceinline__ void publish_lists(const SearchParams &p, const Block
             c = p.k;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wave's stores before its reloads below
         }
-        constexpr int KL = MFMA_MAX_K / 64;
         uint64_t a[KL];
 #pragma unroll
         for (int e = 0; e < KL; e++) {
@@ -388,6 +388,11 @@ __device__ __forceinline__ void publish_lists(const SearchParams &p, const Block
             if (i < p.k) dst[i] = a[e];  // ascending, HVS_KEY_EMPTY padding sorts last
         }
     }
+}
+template <int FOLD, class T>
+__device__ __forceinline__ void publish_lists(const SearchParams &p, const BlockState &b, int q_out0, int s, int wave, int lane) {
+    if (p.k <= 128) publish_lists_kl<FOLD, T, 2>(p, b, q_out0, s, wave, lane);
+    else publish_lists_kl<FOLD, T, MFMA_MAX_K / 64>(p, b, q_out0, s, wave, lane);
 }
 
 // LDS layout: [2 stages][tau][cnt][qinv][bound]
@@ -1085,7 +1090,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // three-product order
     const bool dual = stream && p.split_steps != 0 && bm <= 64;
     if (dual) p.nks = 2 * p.split_steps;
-    p.cap = CAND_MAX;  // >= k + bn for every k <= MFMA_MAX_K: the survivors of one more tile always fit
+    p.cap = k > 128 ? CAND_MAX : CAND_SMALL;  // >= k + bn with room to let an array grow to 2 k between rankings: the survivors of one more tile always fit
     p.dbg = 0;
     if (const char *e = getenv("HVS_DBG")) p.dbg = stream ? 0 : atoi(e);
     p.QT = stream ? 1 : (nA + bm - 1) / bm;
@@ -1239,7 +1244,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < kc) {  // rank by counting: kc <= 128 keys, distinct wherever they are not empty
+    if (t < kc) {  // rank by counting: kc <= MFMA_MAX_K = the block's threads, keys distinct wherever they are not empty
         const uint64_t me = keys[t];
         int rank = 0;
         for (int i = 0; i < kc; i++) {
@@ -1291,8 +1296,33 @@ __global__ void scatter_results_kernel(const float *__restrict__ sub_dist, const
     if (threadIdx.x == 0) cnt[qi] = sub_cnt[j];
 }
 
+// One filter pass + exact rescoring of a batch with kc candidates per query; h_redo[i] = 1 for the queries whose list
+// proves nothing.  Candidates live in workspace 7 (sized by the caller for the largest kc).
+static int rescore_pass(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int kc, int32_t group_filter,
+                        const uint32_t *d_mask, float thr, float eps, int64_t row_begin, int64_t row_end, float *c_dist, int64_t *c_pos,
+                        int32_t *c_cnt, int32_t *d_redo, float *d_dist, int64_t *d_ids, int32_t *d_count, std::vector<int32_t> &h_redo,
+                        int *n_redo) {
+    HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, kc, group_filter, d_mask, thr + eps, row_begin, row_end, c_dist, c_pos, c_cnt, 3));
+    HVS_TRY(hvs_prof_begin(idx));
+    rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
+                                                c_cnt, kc, k, thr, eps, d_dist, d_ids, d_count, d_redo);
+    HVS_HIP(hipGetLastError());
+    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+    h_redo.assign(nq, 0);
+    HVS_HIP(hipMemcpyAsync(h_redo.data(), d_redo, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    *n_redo = 0;
+    for (int i = 0; i < nq; i++) *n_redo += h_redo[i] != 0;
+    return 0;
+}
+
 // *used = false: the route does not apply (k too large for a useful candidate list, or no split copy) and nothing
 // was written.
+// Two list lengths: 4 k candidates (at least 32) first; the queries whose list proves nothing -- a cloud of rows
+// closer to each other than the bound, as tables of text embeddings have around most queries -- go through the filter
+// again as a batch of their own with MFMA_MAX_K candidates (one more product over the hi slabs, against three for
+// scoring every row in full; rescoring 256 rows per query is a few MB), and only what that leaves unproven is searched
+// again in full.  A table on which the short lists fail for most of a batch starts with the long ones from then on.
 int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                        const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids,
                        int32_t *d_count, bool *used) {
@@ -1306,11 +1336,14 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
         idx->filter_skip--;
         return 0;
     }
-    const int kc = 4 * k < 32 ? 32 : (4 * k > MFMA_MAX_K ? MFMA_MAX_K : 4 * k);  // candidates per query: 4 k, at least 32, at most what a list holds
+    const int kc_long = MFMA_MAX_K;
+    int kc = 4 * k < 32 ? 32 : (4 * k > kc_long ? kc_long : 4 * k);  // candidates per query: 4 k, at least 32, at most what a list holds
+    if (const char *e = getenv("HVS_FILTER_KC")) kc = atoi(e) < k ? k : (atoi(e) > kc_long ? kc_long : atoi(e));
+    else if (adapt && idx->filter_long) kc = kc_long;
     const int ld16 = (idx->dim + 63) / 64 * 64;
     const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_pos = up((size_t)nq * kc * 4), o_cnt = o_pos + up((size_t)nq * kc * 8), o_redo = o_cnt + up((size_t)nq * 4);
+    const size_t o_pos = up((size_t)nq * kc_long * 4), o_cnt = o_pos + up((size_t)nq * kc_long * 8), o_redo = o_cnt + up((size_t)nq * 4);
     // behind the candidates: room to search the flagged queries again as a batch of their own (list, embeddings,
     // inverse norms, outputs), unless that would be a workspace of its own size class
     const size_t sub_q_bytes = (size_t)nq * fold * idx->ld * 4;
@@ -1323,18 +1356,55 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     float *c_dist = (float *)ws;
     int64_t *c_pos = (int64_t *)((char *)ws + o_pos);
     int32_t *c_cnt = (int32_t *)((char *)ws + o_cnt), *d_redo = (int32_t *)((char *)ws + o_redo);
-    HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, kc, group_filter, d_mask, thr + eps, row_begin, row_end, c_dist, c_pos, c_cnt, 3));
-    HVS_TRY(hvs_prof_begin(idx));
-    rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
-                                                c_cnt, kc, k, thr, eps, d_dist, d_ids, d_count, d_redo);
-    HVS_HIP(hipGetLastError());
-    HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
-    std::vector<int32_t> redo(nq);
-    HVS_HIP(hipMemcpyAsync(redo.data(), d_redo, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
-    HVS_HIP(hipStreamSynchronize(idx->stream));
+    std::vector<int32_t> redo;
     int n_redo = 0;
-    for (int i = 0; i < nq; i++) n_redo += redo[i] != 0;
+    HVS_TRY(rescore_pass(idx, d_q, d_qinv, nq, fold, k, kc, group_filter, d_mask, thr, eps, row_begin, row_end, c_dist, c_pos, c_cnt, d_redo,
+                         d_dist, d_ids, d_count, redo, &n_redo));
     *used = true;
+    if (adapt && kc < kc_long && 2 * n_redo > nq) idx->filter_long = true;  // this table wants the long lists
+    if (n_redo == 0) {
+        idx->filter_backoff = 0;
+        return 0;
+    }
+    int32_t *d_list = (int32_t *)((char *)ws + o_list);
+    float *sub_q = (float *)((char *)ws + o_subq), *sub_inv = (float *)((char *)ws + o_subinv), *sub_d = (float *)((char *)ws + o_subd);
+    int64_t *sub_i = (int64_t *)((char *)ws + o_subi);
+    int32_t *sub_c = (int32_t *)((char *)ws + o_subc);
+    std::vector<int32_t> list;
+    for (int i = 0; i < nq; i++)
+        if (redo[i]) list.push_back(i);
+    auto gather_flagged = [&]() -> int {
+        HVS_HIP(hipMemcpyAsync(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, idx->stream));
+        gather_queries_kernel<<<(int)list.size(), 256, 0, idx->stream>>>(d_q, d_qinv, d_list, fold, idx->ld, sub_q, sub_inv);
+        HVS_HIP(hipGetLastError());
+        HVS_HIP(hipStreamSynchronize(idx->stream));  // `list` is pageable host memory
+        return 0;
+    };
+    auto scatter_flagged = [&]() -> int {
+        scatter_results_kernel<<<(int)list.size(), 64, 0, idx->stream>>>(sub_d, sub_i, sub_c, d_list, k, d_dist, d_ids, d_count);
+        HVS_HIP(hipGetLastError());
+        return 0;
+    };
+    // second level: the flagged queries with the long lists (a single flagged query: one exact scan instead)
+    if (kc < kc_long && sub_ok && n_redo > 1) {
+        HVS_TRY(gather_flagged());
+        std::vector<int32_t> redo2;
+        int n_redo2 = 0;
+        const int n_sub = (int)list.size();
+        HVS_TRY(rescore_pass(idx, sub_q, sub_inv, n_sub, fold, k, kc_long, group_filter, d_mask, thr, eps, row_begin, row_end, c_dist, c_pos,
+                             c_cnt, d_redo, sub_d, sub_i, sub_c, redo2, &n_redo2));
+        HVS_TRY(scatter_flagged());  // unproven answers travel too and are overwritten below
+        std::vector<int32_t> still;
+        for (int j = 0; j < n_sub; j++)
+            if (redo2[j]) still.push_back(list[j]);
+        list.swap(still);
+        n_redo = n_redo2;
+        if (n_redo == 0) {
+            idx->filter_backoff = 0;
+            return 0;
+        }
+        HVS_HIP(hipStreamSynchronize(idx->stream));  // the scatter reads d_list, which the next level rewrites
+    }
     idx->prof_launches[HVS_PROF_REDO] += n_redo;
     if (adapt) {
         if (2 * n_redo > nq) {
@@ -1343,30 +1413,17 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
         } else
             idx->filter_backoff = 0;
     }
-    if (n_redo == 0) return 0;
     if (n_redo == 1 || (!sub_ok && n_redo <= 8)) {  // one exact scan per flagged query
-        for (int i = 0; i < nq; i++)
-            if (redo[i])
-                HVS_TRY(hvs_search_scan(idx, d_q + (size_t)i * fold * idx->ld, d_qinv + (size_t)i * fold, 1, fold, k, group_filter, d_mask, thr,
-                                        row_begin, row_end, d_dist + (size_t)i * k, d_ids + (size_t)i * k, d_count + i));
+        for (int i : list)
+            HVS_TRY(hvs_search_scan(idx, d_q + (size_t)i * fold * idx->ld, d_qinv + (size_t)i * fold, 1, fold, k, group_filter, d_mask, thr,
+                                    row_begin, row_end, d_dist + (size_t)i * k, d_ids + (size_t)i * k, d_count + i));
         return 0;
     }
     if (n_redo == nq || !sub_ok)  // every list unproven (a table of near-duplicates): the whole batch with all three products
         return hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, 1);
     // the flagged queries as a batch of their own, all three products: one more pass over the rows whatever their number
-    std::vector<int32_t> list;
-    for (int i = 0; i < nq; i++)
-        if (redo[i]) list.push_back(i);
-    int32_t *d_list = (int32_t *)((char *)ws + o_list);
-    float *sub_q = (float *)((char *)ws + o_subq), *sub_inv = (float *)((char *)ws + o_subinv), *sub_d = (float *)((char *)ws + o_subd);
-    int64_t *sub_i = (int64_t *)((char *)ws + o_subi);
-    int32_t *sub_c = (int32_t *)((char *)ws + o_subc);
-    HVS_HIP(hipMemcpyAsync(d_list, list.data(), (size_t)n_redo * 4, hipMemcpyHostToDevice, idx->stream));
-    gather_queries_kernel<<<n_redo, 256, 0, idx->stream>>>(d_q, d_qinv, d_list, fold, idx->ld, sub_q, sub_inv);
-    HVS_HIP(hipGetLastError());
-    HVS_HIP(hipStreamSynchronize(idx->stream));  // `list` is pageable host memory
+    HVS_TRY(gather_flagged());
     HVS_TRY(hvs_search_mfma(idx, sub_q, sub_inv, n_redo, fold, k, group_filter, d_mask, thr, row_begin, row_end, sub_d, sub_i, sub_c, 1));
-    scatter_results_kernel<<<n_redo, 64, 0, idx->stream>>>(sub_d, sub_i, sub_c, d_list, k, d_dist, d_ids, d_count);
-    HVS_HIP(hipGetLastError());
+    HVS_TRY(scatter_flagged());
     return 0;
 }

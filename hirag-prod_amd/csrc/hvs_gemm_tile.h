@@ -7,8 +7,9 @@
 #include "hvs_internal.h"
 
 #define KB 128        // bytes of one tile row per k-step
-#define CAND_MAX 512  // capacity of a candidate array (entries): 8 keys per lane when a wave holds one in registers
-#define MFMA_MAX_K 128
+#define CAND_MAX 1024   // capacity of a candidate array (entries) for k > 128: 16 keys per lane when a wave holds one in registers
+#define CAND_SMALL 512  // ... for k <= 128: 8 keys per lane
+#define MFMA_MAX_K 256
 
 // Block-tile shapes.  BM x BN outputs per block, WM x WN waves, each wave (BM / WM) x (BN / WN) as
 // MT x NT MFMA tiles of 32 x 32.

@@ -840,6 +840,28 @@ extern "C" int hvs_index_prepare(hvs_index *idx, int *out_ready) {
     return 0;
 }
 
+extern "C" int hvs_index_search_copy(hvs_index *idx, int allow, int64_t *out_bytes) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_search_copy: idx is NULL");
+    if (allow >= 0) {
+        idx->split_allowed = allow != 0;
+        if (!idx->split_allowed && idx->split) {  // give the memory back now
+            HVS_HIP(hipSetDevice(idx->device));
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+            (void)hipFree(idx->split);
+            (void)hipFree(idx->split_inv);
+            idx->split = nullptr;
+            idx->split_inv = nullptr;
+            idx->split_cap = idx->split_n = 0;
+        }
+        if (idx->split_allowed) idx->split_failed = false;
+    }
+    if (out_bytes) {
+        const int ld16 = (idx->dim + 63) / 64 * 64;
+        *out_bytes = idx->split ? (int64_t)idx->split_cap * ((int64_t)ld16 * 4 + 4) + HVS_ROWS_SLACK : 0;
+    }
+    return 0;
+}
+
 extern "C" int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64_t *ids, int32_t *group_codes,
                                 uint8_t *deleted) {
     HVS_REQUIRE(idx != nullptr, "hvs_index_export: idx is NULL");

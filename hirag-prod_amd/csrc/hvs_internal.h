@@ -72,12 +72,14 @@ struct hvs_index {
     void *split = nullptr;
     float *split_inv = nullptr;
     int64_t split_cap = 0, split_n = 0;
+    bool split_allowed = true;  // hvs_index_search_copy(idx, 0): never build the copy (the table keeps its own size in HBM)
     bool split_failed = false;  // device memory did not allow the copy (cleared by hvs_index_compact and by an explicit hvs_index_prepare)
     std::string split_why;      // ... and why, for hvs_index_prepare's caller
     // the filter route learns from its own outcome: after a call in which more than half of the candidate lists proved
     // nothing (a table of tight clusters), the next filter_skip calls go straight to the route that scores every row in
     // full; the run of skipped calls doubles with every failure in a row (4, 8, ... 64) and ends with the first success
     int filter_skip = 0, filter_backoff = 0;
+    bool filter_long = false;  // the short candidate lists (4 k) failed for most of a batch: start with the long ones (MFMA_MAX_K)
     int km_filter_skip = 0, km_filter_backoff = 0;  // the same for the k-means assignment's filter pass (more than a quarter of the rows flagged)
 
     hvs_workspace ws[10];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate

@@ -73,6 +73,10 @@ int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64
 int hvs_split_ensure(hvs_index *idx, bool *ok) {
     *ok = false;
     if (idx->dtype != HVS_F32 || idx->split_failed) return 0;
+    if (!idx->split_allowed) {
+        idx->split_why = "the search-side copy is switched off for this table (hvs_index_search_copy); searches stay on the fp32 kernels";
+        return 0;
+    }
     const int ld16 = (idx->dim + 63) / 64 * 64;
     const size_t pitch = (size_t)ld16 * 4;  // two slabs of halves
     if (idx->split_cap < idx->n) {

@@ -403,6 +403,14 @@ class HvsIndex:
             check(self._lib.hvs_index_prepare(self._h, ctypes.byref(ready)))
         return bool(ready.value)
 
+    def search_copy(self, allow: Optional[bool] = None) -> int:
+        """Device bytes the search-side copy of an fp32 table holds (0: none).  ``allow=False`` frees it and keeps the
+        table from ever building one (it costs as much HBM again as the rows); ``allow=True`` lets searches build it."""
+        held = ctypes.c_int64(0)
+        with self._lock:
+            check(self._lib.hvs_index_search_copy(self._h, -1 if allow is None else int(bool(allow)), ctypes.byref(held)))
+        return held.value
+
     def compact(self, renumber_ids: bool = False) -> int:
         """Drop deleted rows and close the gaps (order kept); returns the new row count.  Row
         positions change: position i afterwards is the i-th live row before.  Ids move with their

@@ -207,7 +207,12 @@ class HipVectorStore(BaseVDB):
         index_factory: Optional[Callable[[int, str, int], Any]] = None,
         graph_factory: Optional[Callable[..., Any]] = None,
         coalesce_queries: bool = True,
+        search_copy: bool = True,
     ):
+        """``search_copy``: a ``vector`` (fp32) table serves batched searches, single queries on large tables and
+        k-means from a second, fp16-slab copy of its rows on the 16-bit matrix pipe -- several times faster, and as
+        much device memory again as the rows.  False keeps every table at its own size (fp32 kernels only).  The
+        store logs one line per table when such a copy appears."""
         if vector_type not in ("vector", "halfvec", "bf16"):
             raise ValueError(f"vector_type must be 'vector', 'halfvec' or 'bf16', got {vector_type!r}")
         self.embedding_func = embedding_func
@@ -228,6 +233,8 @@ class HipVectorStore(BaseVDB):
         self._group_codes: Dict[tuple, int] = {}
         self._lock = asyncio.Lock()
         self._coalescer = _SearchCoalescer(self._search_batch) if coalesce_queries else None
+        self.search_copy = bool(search_copy)
+        self._copy_logged: Dict[str, int] = {}
 
     # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
     @classmethod
@@ -255,7 +262,20 @@ class HipVectorStore(BaseVDB):
             if self.embedding_dimension is None:
                 self.embedding_dimension = dim
             table.index = self._make_index(self.embedding_dimension)
+            if not self.search_copy and hasattr(table.index, "search_copy"):
+                table.index.search_copy(False)
         return table.index
+
+    def _note_search_copy(self, table: _Table) -> None:
+        """One log line when a table's search-side copy appears or grows to another size class (nothing here is silent
+        about doubling a table's device memory)."""
+        if self.dtype != "f32" or table.index is None or not hasattr(table.index, "search_copy"):
+            return
+        held = table.index.search_copy()
+        if held and held != self._copy_logged.get(table.name):
+            self._copy_logged[table.name] = held
+            logger.info("[search copy] table '%s': %.2f GB of device memory hold the fp16-slab copy of its fp32 rows "
+                        "(HipVectorStore(search_copy=False) keeps tables at their own size)", table.name, held / 1e9)
 
     @staticmethod
     def _code(mapping: Dict[Any, int], key: Any) -> int:
@@ -596,6 +616,7 @@ class HipVectorStore(BaseVDB):
         filt, group = self._filter_dict(spec)
         dist, ids, cnt = index.search(np.concatenate(queries, axis=0), k=topk, fold=fold, group_filter=group, filter=filt,
                                       max_distance=threshold)
+        self._note_search_copy(self.tables[table_name])
         return [[(int(ids[b][i]), float(dist[b][i])) for i in range(int(cnt[b]))] for b in range(len(queries))]
 
     def _host_mask(self, table: _Table, spec):
@@ -891,6 +912,7 @@ class HipVectorStore(BaseVDB):
             table = self.get_model(name)
             if table.index is not None and hasattr(table.index, "prepare"):
                 out[name] = bool(await asyncio.to_thread(table.index.prepare))
+                self._note_search_copy(table)
         return out
 
     # -- compaction and snapshots (the table outlives deletes and restarts) --------------------------

@@ -40,11 +40,12 @@ enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
  * (16-bit) embeddings.  MFMA: batched contraction on the matrix cores; for fp32 rows it runs on the
  * 16-bit pipe over a split copy of the rows (two fp16 slabs per row, three products, fp32-grade
  * scores; the copy doubles the table's device memory and is built on first use) and falls back to the
- * fp32 MFMA kernel when memory does not allow the copy.  For k <= 64 the split copy is first used as a
- * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k (at most 128) best candidates per
- * query are scored again from the fp32 rows in fp32, and a query whose k-th exact score does not clear the
- * bound of the rows left out is searched again in full -- the exact top-k either way.  MFMA_SPLIT: the
- * three products for every score, no filter.  MFMA_F32: the fp32 MFMA kernel, no copy.
+ * fp32 MFMA kernel when memory does not allow the copy.  For k <= 128 the split copy is first used as a
+ * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k (at most 256) best candidates per
+ * query are scored again from the fp32 rows in fp32, a query whose k-th exact score does not clear the bound of the
+ * rows left out goes through the filter once more with 256 candidates, and what that leaves unproven is searched
+ * again in full -- the exact top-k either way.  MFMA_SPLIT: the three products for every score, no filter.
+ * MFMA_F32: the fp32 MFMA kernel, no copy.  The matrix-pipe routes take k <= 256 (larger k: SCAN).
  * AUTO picks by batch size.
  */
 enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F32 = 3, HVS_ALGO_MFMA_SPLIT = 4 };
@@ -123,6 +124,15 @@ int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
  * copy needed) or device memory does not allow it (searches then stay on the fp32 kernels).
  */
 int hvs_index_prepare(hvs_index *idx, int *out_ready);
+
+/*
+ * That copy costs as much device memory again as the fp32 rows themselves (61 GB for 10M x 1536).  allow = 0: never
+ * build it for this table and free it if it exists -- batched searches, large-table single queries and k-means then
+ * stay on the fp32 kernels; allow = 1 (the state of a new index): build it when a search wants it; allow < 0: change
+ * nothing.  *out_bytes (may be NULL) = device bytes the copy holds now, 0 for none.  No reference counterpart
+ * (nearest: choosing not to CREATE INDEX on a table to save its space).
+ */
+int hvs_index_search_copy(hvs_index *idx, int allow, int64_t *out_bytes);
 
 /*
  * Copy rows [first, first + n) to HOST buffers, for snapshots: rows as stored

@@ -329,8 +329,10 @@ def test_kmeans_sums_are_reproducible_and_cover_small_k(hvs):
 def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     """fp32 table, k <= 64: the hi-slab filter keeps 4 k candidates per query and the answer stands only if the k-th
     exact distance clears the bound of the rows left out.  Clouds of near-duplicates around a query defeat that
-    bound (hundreds of rows within 1e-4 of each other, the filter errs by up to 1e-3): such queries must come back
-    exact all the same -- searched again one by one when they are few, as a whole batch when they are many."""
+    bound (hundreds of rows within 1e-4 of each other, the filter errs by up to 1e-3): such queries go through the
+    filter again with 256 candidates, and what that cannot prove either (clouds of 400 rows here) must come back
+    exact all the same -- searched again by a scan when it is one query, as a batch with all three products
+    otherwise."""
     from hirag_prod_amd import _lib
 
     rng = np.random.default_rng(31337)
@@ -354,9 +356,10 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
         idx.profile(False)
         return out, scans, full
 
-    # two unproven queries out of 200: searched again as a batch of their own, all three products
+    # two unproven queries out of 200: the filter again with the long lists (their clouds hold more rows than a list),
+    # then as a batch of their own, all three products
     (dist, ids, cnt), scans, full = run(q, 10)
-    assert scans == 0 and full == 2
+    assert scans == 0 and full == 3
     for i in range(200):
         parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, label=f"few q={i}")
     # the same with a threshold that cuts inside the cloud and a row range
@@ -371,14 +374,14 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     assert scans == 1 and full == 1
     for i in range(40):
         parity.check_topk(dist1[i], ids1[i], cnt1[i], dm[i], 10, label=f"one q={i}")
-    # every query inside a cloud: the whole batch is searched again with all three products
+    # every query inside a cloud: both filter passes prove nothing, the whole batch is searched again with all three products
     qc = (centre[rng.integers(0, 3, 64)] + 1e-3 * rng.standard_normal((64, d))).astype(np.float32)
     os.environ["HVS_NO_ADAPT"] = "1"  # pin the route: a failed filter pass otherwise keeps the next calls off it
     try:
         (dist, ids, cnt), scans, full = run(qc, 10)
     finally:
         del os.environ["HVS_NO_ADAPT"]
-    assert scans == 0 and full == 2
+    assert scans == 0 and full == 3
     dmc = parity.distance_matrix(rows, qc, "f32")
     for i in range(64):
         parity.check_topk(dist[i], ids[i], cnt[i], dmc[i], 10, label=f"many q={i}")
@@ -389,7 +392,7 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     assert np.array_equal(ids2, ids) and np.array_equal(cnt2, cnt)
     for _ in range(3):
         idx.search(qc, k=10, algo="mfma")
-    (dist3, ids3, cnt3), scans, full = run(q, 10)  # run() searches twice: the filter is back, and proves 198 of 200 lists
+    (dist3, ids3, cnt3), scans, full = run(q, 10)  # run() searches twice: the filter is back (with the long lists from the start: the table remembers that too), and proves 198 of 200 lists
     assert scans == 0 and full == 2
     for i in range(200):
         parity.check_topk(dist3[i], ids3[i], cnt3[i], dm[i], 10, label=f"after the back-off q={i}")
@@ -400,6 +403,34 @@ def test_filter_pass_falls_back_when_its_bound_proves_nothing(hvs):
     keep[1000:1030] = True
     for i in range(20):
         parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, keep=keep, label=f"short q={i}")
+    idx.close()
+
+
+def test_filter_route_settles_clustered_tables_with_the_long_lists(hvs):
+    """A table of tight clusters (about 120 rows within 1e-4 .. 1e-3 of each other around every query, the next cluster far
+    away): 40 candidates prove nothing, 256 hold the whole cluster and prove everything -- no query is searched again in
+    full, and after one such batch the table starts with the long lists."""
+    from hirag_prod_amd import _lib
+
+    rng = np.random.default_rng(4242)
+    d, n_clusters, per = 192, 60, 120
+    centres = rng.standard_normal((n_clusters, d)).astype(np.float32)
+    rows = (np.repeat(centres, per, axis=0) + 2e-2 * rng.standard_normal((n_clusters * per, d))).astype(np.float32)
+    rows = rows[rng.permutation(len(rows))]
+    q = (centres[rng.integers(0, n_clusters, 96)] + 2e-2 * rng.standard_normal((96, d))).astype(np.float32)
+    dm = parity.distance_matrix(rows, q, "f32")
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    for call, launches in ((0, 2), (1, 1)):  # first call: short lists, then long ones for the flagged queries; second: long ones at once
+        idx.profile(True)
+        idx.profile_reset()
+        dist, ids, cnt = idx.search(q, k=10, algo="mfma")
+        full, again = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)[1], idx.profile_get(_lib.HVS_PROF_REDO)[1]
+        scans = idx.profile_get(_lib.HVS_PROF_SCAN)[1]
+        idx.profile(False)
+        assert (full, again, scans) == (launches, 0, 0), (call, full, again, scans)
+        for i in range(96):
+            parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, label=f"clustered call {call} q={i}")
     idx.close()
 
 

@@ -26,6 +26,7 @@ FIXED = [  # (dim, rows, query groups, fold, k)
     (127, 31, 40, 1, 40), (129, 5000, 17, 4, 128), (200, 4097, 129, 1, 1), (777, 2500, 6, 2, 50),
     (96, 3000, 256, 1, 10), (130, 700, 100, 2, 100), (50, 260, 60, 3, 128),  # 129 - 256 A rows
     (40, 1500, 300, 1, 10), (72, 900, 128, 4, 16),  # two query tiles of 256 A rows
+    (100, 3000, 40, 1, 256), (48, 2000, 140, 2, 200),  # k beyond 128 on the matrix pipe (candidate arrays of 1024)
 ]
 
 
@@ -66,7 +67,7 @@ def test_random_shapes_all_routes(hvs, dtype, stream, monkeypatch):
             if fold > 4:
                 routes = ["scan"]
             for algo in routes:
-                if algo != "scan" and k > 128:
+                if algo != "scan" and k > 256:
                     continue
                 dist, ids, cnt = idx.search(q, k=k, fold=fold, group_filter=gf, max_distance=thr, algo=algo)
                 for i in range(nq):

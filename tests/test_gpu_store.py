@@ -124,3 +124,44 @@ def test_small_kb_workload():
 
     store_cases.run(go())
     s.close()
+
+
+def test_search_copy_knob_and_log_line(caplog):
+    """A `vector` (fp32) store builds a second copy of a table for the 16-bit matrix pipe on its first batched search and
+    says so in one log line; `search_copy=False` keeps the table at its own size, and the answers are the same."""
+    import logging
+
+    import hirag_prod_amd.store as st
+
+    async def go(search_copy):
+        s = st.HipVectorStore.create(store_cases.make_embedding_func(), vector_type="vector", search_copy=search_copy)
+        await s._init_vdb(embedding_dimension=store_cases.DIM)
+        props = [store_cases.chunk_props(i) for i in range(400)]
+        await s.upsert_texts([p["text"] for p in props], props, "Chunks")
+        index = s.tables["Chunks"].index
+        assert index.search_copy() == 0
+        ready = await s.prepare("Chunks")
+        held = index.search_copy()
+        res = await s.query(["text ws1 kb1 11", "text ws1 kb1 12"], "ws1", "kb1", "Chunks", topk=10, distance_threshold=1.5)
+        s.close()
+        return ready["Chunks"], held, [(r["documentKey"], round(r["distance"], 5)) for r in res]
+
+    with caplog.at_level(logging.INFO, logger="hirag_prod_amd.store"):
+        ready, held, with_copy = store_cases.run(go(True))
+    assert ready and held >= 400 * store_cases.DIM * 4
+    assert sum("[search copy] table 'Chunks'" in r.getMessage() for r in caplog.records) == 1
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="hirag_prod_amd.store"):
+        ready, held, without = store_cases.run(go(False))
+    assert not ready and held == 0
+    assert not any("[search copy]" in r.getMessage() for r in caplog.records)
+    assert [k for k, _ in with_copy] == [k for k, _ in without]
+    # an index that had a copy gives the memory back when told to
+    import hirag_prod_amd as hvs
+
+    idx = hvs.HvsIndex(64, "f32")
+    idx.add(np.random.default_rng(0).standard_normal((1000, 64)).astype(np.float32))
+    assert idx.prepare() and idx.search_copy() > 0
+    assert idx.search_copy(False) == 0 and not idx.prepare()
+    assert idx.search_copy(True) == 0 and idx.prepare() and idx.search_copy() > 0
+    idx.close()
