@@ -1121,7 +1121,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         const size_t part_bytes = (size_t)nq * S * k * 8;
         const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
         // arrival counters of lockstep_arrive: when the grid fits the chip at once (it is sized to) and blocks share streams
-        const bool lockstep = !stream && (S & 7) == 0 && !getenv("HVS_NO_LOCKSTEP");
+        const bool lockstep = !stream && (S & 7) == 0 && grid <= (big ? 256 : (small ? 1024 : 512)) && !getenv("HVS_NO_LOCKSTEP");
         const size_t ls_bytes = lockstep ? (size_t)8 * S * 4 : 0;
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
         HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512 + ls_bytes, &bufB));

@@ -417,7 +417,7 @@ template <int DT, class T, bool TOP2 = false> static int launch_assign(AssignPar
     if (S < 1) S = 1;
     p.S = S;
     if (p.lockstep) HVS_HIP(hipMemsetAsync(p.lockstep, 0, 4096 * 4, st));
-    if ((S & 7) != 0 || S > 4096) p.lockstep = nullptr;
+    if ((S & 7) != 0 || S > 4096 || p.CT * S > (T::GT == 256 ? 512 : 256)) p.lockstep = nullptr;  // only when every block is resident at once
     const size_t lds = assign_lds_bytes<T>();
     HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_assign_kernel<DT, T, TOP2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
