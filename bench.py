@@ -583,16 +583,26 @@ def main():
             result["cpu_baseline"] = cpu_baseline(min(16, os.cpu_count() or 1), idx.export(0, sample)[0])
         else:
             result["cpu_baseline"] = None
-    # the other BASELINE configurations, each on a freshly filled table of its own (one GPU only: they are per-GPU figures)
+    # the other BASELINE configurations, each on a freshly filled table of its own (one GPU only: they are per-GPU figures).
+    # A leg that fails says so in its place; the headline line is printed regardless.
+    def aux_leg(name, fn, *a):
+        try:
+            result["aux"][name] = fn(*a)
+        except Exception as e:  # noqa: BLE001 -- reported, not swallowed
+            import traceback
+
+            traceback.print_exc()
+            result["aux"][name] = {"error": f"{type(e).__name__}: {e}"}
+
     if world == 1 and not args.no_aux:
-        result["aux"]["cfg4_kmeans"] = leg_cfg4(idx, hvs, _lib, torch, dev, hi - lo)
+        aux_leg("cfg4_kmeans", leg_cfg4, idx, hvs, _lib, torch, dev, hi - lo)
     if world > 1:
         dist.barrier()
     idx.close()
     if world == 1 and not args.no_aux:
-        result["aux"]["cfg2"] = leg_cfg2(hvs, _lib, torch, dev)
-        result["aux"]["cfg5_shard"] = leg_cfg5(hvs, _lib, torch, dev)
-        result["aux"]["clustered"] = leg_clustered(hvs, _lib, torch, dev, args.batch)
+        aux_leg("cfg2", leg_cfg2, hvs, _lib, torch, dev)
+        aux_leg("cfg5_shard", leg_cfg5, hvs, _lib, torch, dev)
+        aux_leg("clustered", leg_clustered, hvs, _lib, torch, dev, args.batch)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
