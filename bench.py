@@ -303,6 +303,50 @@ def leg_clustered(hvs, _lib, torch, dev, batch):
     return out
 
 
+# Per-configuration legs that fill a table of their own: each runs in a child process after the headline table is
+# freed, so that whatever happens in one of them (a failed assertion, a device fault that ends its process) costs that
+# leg and nothing else -- the parent prints the one JSON line either way.
+CHILD_LEGS = {"cfg2": leg_cfg2, "cfg5_shard": leg_cfg5, "clustered": leg_clustered}
+
+
+def run_child_leg(name, batch):
+    import torch
+
+    import hirag_prod_amd as hvs
+    from hirag_prod_amd import _lib
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    extra = (batch,) if name == "clustered" else ()
+    print("LEG-RESULT " + json.dumps(CHILD_LEGS[name](hvs, _lib, torch, dev, *extra)), flush=True)
+
+
+def child_leg(name, batch, timeout_s=600):
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name, "--batch", str(batch)], capture_output=True, text=True,
+                           timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"leg {name}: no result within {timeout_s} s"}
+    except OSError as e:  # no child process to be had here: run the leg in this one
+        print(f"bench.py: could not start a child process for leg {name} ({e}); running it in-process", file=sys.stderr, flush=True)
+        try:
+            import torch
+
+            import hirag_prod_amd as hvs
+            from hirag_prod_amd import _lib
+
+            dev = torch.device("cuda", torch.cuda.current_device())
+            return CHILD_LEGS[name](hvs, _lib, torch, dev, *((batch,) if name == "clustered" else ()))
+        except Exception as e2:  # noqa: BLE001 -- reported in the leg's place
+            return {"error": f"leg {name}: {type(e2).__name__}: {e2}"}
+    for line in r.stdout.splitlines():
+        if line.startswith("LEG-RESULT "):
+            return json.loads(line[len("LEG-RESULT "):])
+    return {"error": f"leg {name}: exit status {r.returncode}", "stderr_tail": r.stderr[-800:]}
+
+
 def measured_traffic(rows_per_gpu, batch):
     """HBM-side bytes per launch of the search kernel from the committed counter passes (rocprofv3
     cannot be driven from inside this process); None when they were taken at another size."""
@@ -326,7 +370,10 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--leg", choices=sorted(CHILD_LEGS), help="run one per-configuration leg alone and print its JSON object (used by the main run)")
     args = ap.parse_args()
+    if args.leg:
+        return run_child_leg(args.leg, args.batch)
 
     import torch
     import torch.distributed as dist
@@ -600,9 +647,9 @@ def main():
         dist.barrier()
     idx.close()
     if world == 1 and not args.no_aux:
-        aux_leg("cfg2", leg_cfg2, hvs, _lib, torch, dev)
-        aux_leg("cfg5_shard", leg_cfg5, hvs, _lib, torch, dev)
-        aux_leg("clustered", leg_clustered, hvs, _lib, torch, dev, args.batch)
+        torch.cuda.empty_cache()
+        for name in ("cfg2", "cfg5_shard", "clustered"):
+            result["aux"][name] = child_leg(name, args.batch)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
