@@ -154,3 +154,19 @@ def test_shard_range_covers_rows():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_bench_child_leg_reports_a_failed_leg_in_its_place():
+    """The per-configuration legs of bench.py run in child processes; one that dies (here: no GPU in this container)
+    must come back as an error object, not as an exception in the parent."""
+    import importlib.util
+
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the leg would run for real")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.child_leg("cfg2", 64, timeout_s=300)
+    assert set(out) >= {"error"} and "exit status" in out["error"], out
+    assert "HIP" in out.get("stderr_tail", "") or "hip" in out.get("stderr_tail", "").lower(), out
