@@ -118,7 +118,7 @@ int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
 /*
  * Bring the search-side copy of an fp32 table up to date ahead of the first search (it is otherwise built by the
  * first batched search): the [hi | lo] fp16 split copy that batched searches contract and that searches with
- * k <= 64, single queries on large tables included, use as a filter before exact fp32 scoring.  The nearest
+ * k <= 128 (single queries on large tables: k <= 64) use as a filter before exact fp32 scoring.  The nearest
  * thing in the reference is the index DDL of PGVector._init_vdb (pgvector.py:704-726): work done once so that
  * queries are fast.  *out_ready (may be NULL) = 1 when the copy is in place, 0 when the table is 16-bit (no
  * copy needed) or device memory does not allow it (searches then stay on the fp32 kernels).
