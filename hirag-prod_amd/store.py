@@ -23,6 +23,7 @@ import asyncio
 import logging
 import math
 import time
+from collections.abc import Mapping
 from datetime import datetime
 from typing import Any, Callable, Dict, List, Literal, Optional, Union
 
@@ -57,6 +58,78 @@ class StoredVector(list):
         return list(self)
 
 
+class _RowView(Mapping):
+    """One metadata row of a ``_RowStore``, read in place: behaves like the row's dict (every column of the table is a
+    key; a column the row was inserted without reads ``None``, which is what ``dict.get`` gave before)."""
+
+    __slots__ = ("_cols", "_names", "_pos")
+
+    def __init__(self, cols, names, pos):
+        self._cols, self._names, self._pos = cols, names, pos
+
+    def __getitem__(self, key):
+        return self._cols[key][self._pos]
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+
+class _RowStore:
+    """The metadata rows of a table, column by column: one Python list per column instead of one dict per row.  A dict
+    of a dozen entries costs about 400 bytes beyond the values it points to, a column slot costs 8 -- at the 12.5M rows
+    of one GPU's share of a 100M-row table that is 5 GB of host memory against 1.2 GB.  List-like over positions:
+    ``rows[pos]`` is a read-only mapping (or ``None`` for a deleted row), ``rows[pos] = None`` deletes, ``append`` takes a
+    dict; deleting drops the references the row held."""
+
+    def __init__(self, columns):
+        self.names = tuple(c for c in columns if c != "vector")
+        self._cols = {c: [] for c in self.names}
+        self._alive = bytearray()
+
+    def __len__(self):
+        return len(self._alive)
+
+    def append(self, row) -> None:
+        get = row.get if row is not None else (lambda c: None)
+        for c, col in self._cols.items():
+            col.append(get(c))
+        self._alive.append(0 if row is None else 1)
+
+    def extend(self, rows) -> None:
+        for row in rows:
+            self.append(row)
+
+    def __getitem__(self, pos):
+        if not self._alive[pos]:  # IndexError past the end, like a list
+            return None
+        return _RowView(self._cols, self.names, pos if pos >= 0 else pos + len(self._alive))
+
+    def __setitem__(self, pos, row) -> None:
+        self._alive[pos] = 0 if row is None else 1
+        for c, col in self._cols.items():
+            col[pos] = None if row is None else row.get(c)
+
+    def __iter__(self):
+        cols, names, alive = self._cols, self.names, self._alive
+        for pos in range(len(alive)):
+            yield _RowView(cols, names, pos) if alive[pos] else None
+
+    def column(self, name):
+        """The column's list, position-aligned (entries of deleted rows are None)."""
+        return self._cols[name]
+
+    def take(self, positions) -> "_RowStore":
+        """A new store holding the rows at ``positions``, in that order (compaction)."""
+        out = _RowStore(self.names)
+        for c, col in self._cols.items():
+            out._cols[c] = [col[p] for p in positions]
+        out._alive = bytearray(self._alive[p] for p in positions)
+        return out
+
+
 class _Table:
     """Host-side state of one table: metadata rows, primary-key map, filter columns."""
 
@@ -64,7 +137,7 @@ class _Table:
         self.name = name
         self.columns, self.pk, self.has_vector = TABLES[name]
         self.colset = set(self.columns)
-        self.rows: List[Optional[dict]] = []  # position -> row (None = deleted)
+        self.rows = _RowStore(self.columns)  # position -> row mapping (None = deleted), stored by column
         self.pk_map: Dict[tuple, int] = {}
         self.key_index: Dict[str, Dict[Any, List[int]]] = {}
         self.index = None  # HvsIndex for embedded tables
@@ -933,7 +1006,7 @@ class HipVectorStore(BaseVDB):
                             left = await asyncio.to_thread(table.index.compact, True)
                             if left != len(keep):
                                 raise RuntimeError(f"table {name}: {left} rows left on the device, {len(keep)} on the host")
-                        table.rows = [table.rows[pos] for pos in keep]
+                        table.rows = table.rows.take(keep.tolist())
                         for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
                             setattr(table, col, getattr(table, col)[:n][keep].copy())
                         table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
@@ -986,7 +1059,7 @@ class HipVectorStore(BaseVDB):
             for name, table in self.tables.items():
                 with open(os.path.join(directory, f"{name}.rows.jsonl"), "w") as fh:
                     for row in table.rows:
-                        fh.write(json.dumps(row, default=self._json_default) + "\n")
+                        fh.write(json.dumps(None if row is None else dict(row), default=self._json_default) + "\n")
                 if table.index is not None:
                     await asyncio.to_thread(write_index, table.index, os.path.join(directory, f"{name}.hvs"))
             with open(os.path.join(directory, "store.json"), "w") as fh:  # last: its presence marks a complete snapshot
@@ -1015,7 +1088,8 @@ class HipVectorStore(BaseVDB):
         for name, info in meta["tables"].items():
             table = store.get_model(name)
             with open(os.path.join(directory, f"{name}.rows.jsonl")) as fh:
-                table.rows = [json.loads(line, object_hook=cls._json_hook) for line in fh]
+                table.rows = _RowStore(table.columns)
+                table.rows.extend(json.loads(line, object_hook=cls._json_hook) for line in fh)
             if len(table.rows) != info["rows"]:
                 raise ValueError(f"{directory}: {name}.rows.jsonl holds {len(table.rows)} rows, store.json says {info['rows']}")
             n = len(table.rows)

@@ -71,3 +71,33 @@ def test_store_is_a_basevdb_and_refuses_without_gpu():
             store_cases.run(s._init_vdb(embedding_dimension=8))
     with pytest.raises(ValueError):
         st.HipVectorStore(None, vector_type="int8")
+
+
+def test_row_store_behaves_like_the_list_of_dicts_it_replaces():
+    import json
+
+    import hirag_prod_amd.store as st
+
+    rows = st._RowStore(["documentKey", "text", "vector", "chunkIdx"])
+    assert rows.names == ("documentKey", "text", "chunkIdx") and len(rows) == 0
+    rows.append({"documentKey": "a", "text": "t0", "chunkIdx": 0, "not_a_column": 1})
+    rows.append({"documentKey": "b"})  # a column the row came without reads None
+    rows.append(None)  # a deleted row of a snapshot
+    rows.extend([{"documentKey": "d", "chunkIdx": 3}])
+    assert len(rows) == 4 and rows[2] is None
+    r = rows[1]
+    assert r["documentKey"] == "b" and r.get("text") is None and r.get("nope", 7) == 7 and "text" in r and "vector" not in r
+    assert dict(rows[0]) == {"documentKey": "a", "text": "t0", "chunkIdx": 0}
+    assert json.loads(json.dumps(dict(rows[3]))) == {"documentKey": "d", "text": None, "chunkIdx": 3}
+    assert rows[-1]["documentKey"] == "d"
+    with pytest.raises(IndexError):
+        rows[4]
+    with pytest.raises(KeyError):
+        rows[0]["nope"]
+    rows[0] = None  # delete: the view a caller still holds reads None from then on, the row itself is gone
+    assert rows[0] is None and rows.column("text")[0] is None
+    assert [None if x is None else x["documentKey"] for x in rows] == [None, "b", None, "d"]
+    kept = rows.take([1, 3])
+    assert len(kept) == 2 and [x["documentKey"] for x in kept] == ["b", "d"] and kept[1]["chunkIdx"] == 3
+    rows[2] = {"documentKey": "c", "text": "again"}
+    assert rows[2]["text"] == "again"
