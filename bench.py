@@ -298,6 +298,10 @@ def leg_clustered(hvs, _lib, torch, dev, batch):
         "filter_route_every_call": fixed, "filter_route_every_call_qps": batch * 1e3 / fixed["median_ms"],
         "default_route_with_back_off": auto, "default_route_qps": batch * 1e3 / auto["median_ms"],
         "ids_equal_to_three_product_route": float((i_f == i_s).float().mean().item()),
+        # inside a cluster hundreds of rows lie within a few 1e-7 of each other: the two routes agree on the distances and
+        # may order such rows differently (the parity bar allows swaps between distances that tie within 1e-6)
+        "max_abs_distance_diff_vs_three_product_route": float((d_f - d_s).abs().max().item()),
+        "ids_equal_or_tied_within_1e-6": float(((i_f == i_s) | ((d_f - d_s).abs() <= 1e-6)).float().mean().item()),
     })
     idx.close()
     return out
