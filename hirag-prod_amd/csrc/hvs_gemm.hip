@@ -1081,6 +1081,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // tile shape of the two-stage kernel: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
     bool big = kdt != HVS_F32 && nA > Tile128::BM;
     if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
+    // fp32 rows take the 256 x 256 tile too when it pads no more query rows than the 128 tile would: half the barriers
+    // and LDS-DMA issues per MFMA and two blocks per corpus stream instead of four (4096 queries x 2M x 1536: 177.4 ms
+    // against 182.5 ms, 111 GB of fabric reads per launch against 164 GB)
+    if (kdt == HVS_F32) big = nA > Tile128::BM && (nA + Tile256::BM - 1) / Tile256::BM * Tile256::BM == (nA + Tile128::BM - 1) / Tile128::BM * Tile128::BM;
+    if (const char *e = getenv("HVS_F32_TILE")) big = kdt == HVS_F32 ? atoi(e) == 256 && nA > Tile128::BM : big;  // 128 / 256 forces the shape for fp32 rows
     bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
     if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
     const int bm = stream ? (nA <= 32 ? 32 : (nA <= 64 ? 64 : 128)) : (big ? Tile256::BM : (small ? Tile64::BM : Tile128::BM));
@@ -1137,7 +1142,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         if (stream) {
             if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, dual, pf, grid, idx->stream, pp));
             else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, pp));
-        } else if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, pp)));
+        } else if (kdt == HVS_F32 && big) HVS_TRY((launch_search<HVS_F32, Tile256>(pf, grid, idx->stream, pp)));
+        else if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, pp)));
