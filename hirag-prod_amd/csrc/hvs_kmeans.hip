@@ -510,7 +510,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         p.ld_bytes = ld * 4;
         p.nks = ldc / 32;
     }
-    const bool big = split && K > Tile128::BM;
+    // the 256 x 256 tile: split operands beyond one 128-centroid tile; fp32 operands when it pads no more centroids than the 128 tile
+    const bool big = K > Tile128::BM && (split || (K + Tile256::BM - 1) / Tile256::BM * Tile256::BM == (K + Tile128::BM - 1) / Tile128::BM * Tile128::BM);
     const int bm = big ? Tile256::BM : Tile128::BM;
     void *best = nullptr;
     HVS_TRY(hvs_ws_get(idx, 1, (size_t)((K + bm - 1) / bm) * n * 8, &best));
@@ -617,7 +618,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         }
     }
     if (!done) {
-        if (!split) HVS_TRY((launch_assign<HVS_F32, Tile128>(p, n, st)));
+        if (!split && big) HVS_TRY((launch_assign<HVS_F32, Tile256>(p, n, st)));
+        else if (!split) HVS_TRY((launch_assign<HVS_F32, Tile128>(p, n, st)));
         else if (!big) HVS_TRY((launch_assign<HVS_F16, Tile128>(p, n, st)));
         else HVS_TRY((launch_assign<HVS_F16, Tile256>(p, n, st)));
         int rg = (int)((n + 255) / 256);
