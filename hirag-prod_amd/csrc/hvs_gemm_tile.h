@@ -138,7 +138,7 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
     };
     if (DT == HVS_F32) {
         // 16 groups (s, j) of MT NT MFMAs per k-step; the pieces go after every (16 / PIECES)-th group
-        constexpr int EVERY = 16 / PIECES;
+        constexpr int EVERY = 16 / PIECES;  // (all pieces in the first half of the step: 177.8 - 180.4 ms against 176.3 on 4096 x 2M fp32 -- a step is long enough here)
         static_assert(EVERY >= 1 && 16 % PIECES == 0, "pieces must divide the MFMA groups");
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -165,9 +165,13 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
         // itself.  The slice loop is software-pipelined over half-slices: while the MFMAs of the first MT/2
         // row blocks run, the fragments of the second half arrive; while those run, the first half of the
         // NEXT slice arrives (A fragments reuse the registers just consumed, X fragments alternate
-        // between two sets).  One LDS-DMA piece goes after each half-slice (8 per k-step).
+        // between two sets).  The LDS-DMA pieces of the next step go out after the first half-slices.
         constexpr int HALF = MT / 2;
         static_assert(MT % 2 == 0 && PIECES == 8, "half-slice pipeline: even MT, one piece per half-slice");
+        // LDS-DMA pieces of the next step per half-slice gap: 4, i.e. all 8 are out after the first two gaps.  One per gap
+        // (the last one issued just ahead of the step barrier) left a good part of its latency exposed at every step:
+        // 2M x 1536 f16 x 4096 queries 970 -> 1 005 TFLOP/s, K loop alone 1 085 -> 1 123; 2 per gap 1 002, all 8 in the first gap 999
+        constexpr int DMA_PER_GAP = 4;
         f32x4 fa[MT], fb[2][NT];
 #pragma unroll
         for (int t = 0; t < HALF; t++) fa[t] = frag(As, t, h);
@@ -182,7 +186,10 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = 0; mt < HALF; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s);
+            // LDS-DMA pieces of the next step: DMA_PER_GAP after each half-slice until all 8 are out
+#pragma unroll
+            for (int i = 0; i < DMA_PER_GAP; i++)
+                if ((2 * s) * DMA_PER_GAP + i < PIECES) dma_piece<T>(sa, sb, next_stage, next_off, wave, (2 * s) * DMA_PER_GAP + i);
             __builtin_amdgcn_sched_barrier(0);
             if (s < 3) {
 #pragma unroll
@@ -195,7 +202,9 @@ __device__ __forceinline__ void compute_step(f32x16 (&acc)[T::MT][T::NT], const 
             for (int mt = HALF; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) acc[mt][nt] = mfma16<DT>(fa[mt], fb[s & 1][nt], acc[mt][nt]);
-            dma_piece<T>(sa, sb, next_stage, next_off, wave, 2 * s + 1);
+#pragma unroll
+            for (int i = 0; i < DMA_PER_GAP; i++)
+                if ((2 * s + 1) * DMA_PER_GAP + i < PIECES) dma_piece<T>(sa, sb, next_stage, next_off, wave, (2 * s + 1) * DMA_PER_GAP + i);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
