@@ -950,7 +950,7 @@ int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, in
     if (use_split) {
         char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
         float *a_split_inv = (float *)(a_split + up((size_t)m * ld16 * 4));
-        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, m, lda, lda, ld16, a_split, a_split_inv));
+        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, m, lda, lda, ld16, a_split, a_split_inv, nullptr, nullptr));
         p.A = a_split;
         p.q_inv = a_split_inv;
         p.lda_bytes = p.ld_bytes = ld16 * 4;
@@ -989,7 +989,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     void *a_ws = nullptr;
     const size_t a_bytes = ((size_t)nA * lda_bytes + 255) & ~(size_t)255;
     const size_t a_inv_bytes = ((size_t)nA * 4 + 255) & ~(size_t)255;
-    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + a_split_bytes + (((size_t)nq * 4 + 255) & ~(size_t)255), &a_ws));  // + tau0 of a sample pass
+    const size_t tau0_bytes = ((size_t)nq * 4 + 255) & ~(size_t)255;  // tau0 of a sample pass
+    HVS_TRY(hvs_ws_get(idx, 4, a_bytes + a_inv_bytes + a_split_bytes + tau0_bytes + a_inv_bytes, &a_ws));  // ... + q_rel of split queries
     float *A_inv = (float *)((char *)a_ws + a_bytes);
     if (idx->dtype == HVS_F32)
         build_a_kernel<float><<<nA, 256, 0, idx->stream>>>(d_q, d_qinv, (float *)a_ws, A_inv, fold, pf, idx->ld, lda);
@@ -1059,7 +1060,9 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (use_split) {
         char *a_split = (char *)a_ws + a_bytes + a_inv_bytes;
         float *a_split_inv = (float *)(a_split + (((size_t)nA * ld16 * 4 + 255) & ~(size_t)255));
-        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, nA, lda, lda, ld16, a_split, a_split_inv));
+        float *a_rel = (float *)((char *)a_ws + a_bytes + a_inv_bytes + a_split_bytes + tau0_bytes);
+        HVS_TRY(hvs_split_rows(idx->stream, (const float *)a_ws, A_inv, 0, nA, lda, lda, ld16, a_split, a_split_inv, a_rel, nullptr));
+        idx->q_rel = a_rel;
         kdt = HVS_F16;
         p.A = a_split;
         p.q_inv = a_split_inv;
@@ -1215,9 +1218,10 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
                                                        const int64_t *__restrict__ ids, const float *__restrict__ q,
                                                        const float *__restrict__ q_inv, int fold, const float *__restrict__ cand_dist,
                                                        const int64_t *__restrict__ cand_pos, const int32_t *__restrict__ cand_cnt, int kc,
-                                                       int k, float thr, float eps, float *__restrict__ out_dist,
-                                                       int64_t *__restrict__ out_ids, int32_t *__restrict__ out_count,
-                                                       int32_t *__restrict__ redo) {
+                                                       int k, float thr, float eps, const float *__restrict__ q_rel, int q_rel_stride,
+                                                       const uint32_t *__restrict__ x_rel_max, float eps_tail,
+                                                       float *__restrict__ out_dist, int64_t *__restrict__ out_ids,
+                                                       int32_t *__restrict__ out_count, int32_t *__restrict__ redo) {
     __shared__ uint64_t keys[MFMA_MAX_K], sorted[MFMA_MAX_K];
     const int qi = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1272,7 +1276,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
         out_count[qi] = n_valid < k ? n_valid : k;
         bool ok = true;
         if (n_c >= kc) {  // the list was cut at kc
-            const float bound = cand_dist[(size_t)qi * kc + kc - 1] - eps;  // no row outside the list is closer than this
+            // the bound of these operands (split_rows_kernel measured how far each lies from its hi slab), never more than
+            // the bound of the rounding unit
+            float rq = 0.0f;
+            for (int j = 0; j < fold; j++) rq = fmaxf(rq, q_rel[(size_t)qi * q_rel_stride + j]);
+            const float rx = __uint_as_float(*x_rel_max);
+            const float eps_q = fminf(eps, rx + rq * (1.0f + rx) + eps_tail);
+            const float bound = cand_dist[(size_t)qi * kc + kc - 1] - eps_q;  // no row outside the list is closer than this
             const bool proven = n_valid >= k && hvs_unord((uint32_t)(sorted[k - 1] >> 32)) + 2e-6f < bound;
             ok = proven || bound >= thr;
         }
@@ -1305,13 +1315,15 @@ __global__ void scatter_results_kernel(const float *__restrict__ sub_dist, const
 // One filter pass + exact rescoring of a batch with kc candidates per query; h_redo[i] = 1 for the queries whose list
 // proves nothing.  Candidates live in workspace 7 (sized by the caller for the largest kc).
 static int rescore_pass(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int kc, int32_t group_filter,
-                        const uint32_t *d_mask, float thr, float eps, int64_t row_begin, int64_t row_end, float *c_dist, int64_t *c_pos,
-                        int32_t *c_cnt, int32_t *d_redo, float *d_dist, int64_t *d_ids, int32_t *d_count, std::vector<int32_t> &h_redo,
+                        const uint32_t *d_mask, float thr, float eps, float eps_tail, int64_t row_begin, int64_t row_end, float *c_dist,
+                        int64_t *c_pos, int32_t *c_cnt, int32_t *d_redo, float *d_dist, int64_t *d_ids, int32_t *d_count, std::vector<int32_t> &h_redo,
                         int *n_redo) {
     HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, kc, group_filter, d_mask, thr + eps, row_begin, row_end, c_dist, c_pos, c_cnt, 3));
+    HVS_REQUIRE(idx->q_rel && idx->split_rel, "hvs_search: the filter pass left no error measure of its operands");
     HVS_TRY(hvs_prof_begin(idx));
     rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
-                                                c_cnt, kc, k, thr, eps, d_dist, d_ids, d_count, d_redo);
+                                                c_cnt, kc, k, thr, eps, idx->q_rel, padded_fold(fold), idx->split_rel, eps_tail, d_dist, d_ids,
+                                                d_count, d_redo);
     HVS_HIP(hipGetLastError());
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     h_redo.assign(nq, 0);
@@ -1347,7 +1359,8 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     if (const char *e = getenv("HVS_FILTER_KC")) kc = atoi(e) < k ? k : (atoi(e) > kc_long ? kc_long : atoi(e));
     else if (adapt && idx->filter_long) kc = kc_long;
     const int ld16 = (idx->dim + 63) / 64 * 64;
-    const float eps = 9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f;
+    const float eps_tail = (float)ld16 * 6.0e-8f + 1e-6f;  // fp32 accumulation of the products, roundings of the distance formula
+    const float eps = 9.78e-4f + eps_tail;                // whatever the operands; the rescoring kernel tightens it to theirs
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_pos = up((size_t)nq * kc_long * 4), o_cnt = o_pos + up((size_t)nq * kc_long * 8), o_redo = o_cnt + up((size_t)nq * 4);
     // behind the candidates: room to search the flagged queries again as a batch of their own (list, embeddings,
@@ -1364,7 +1377,7 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
     int32_t *c_cnt = (int32_t *)((char *)ws + o_cnt), *d_redo = (int32_t *)((char *)ws + o_redo);
     std::vector<int32_t> redo;
     int n_redo = 0;
-    HVS_TRY(rescore_pass(idx, d_q, d_qinv, nq, fold, k, kc, group_filter, d_mask, thr, eps, row_begin, row_end, c_dist, c_pos, c_cnt, d_redo,
+    HVS_TRY(rescore_pass(idx, d_q, d_qinv, nq, fold, k, kc, group_filter, d_mask, thr, eps, eps_tail, row_begin, row_end, c_dist, c_pos, c_cnt, d_redo,
                          d_dist, d_ids, d_count, redo, &n_redo));
     *used = true;
     if (adapt && kc < kc_long && 2 * n_redo > nq) idx->filter_long = true;  // this table wants the long lists
@@ -1397,7 +1410,7 @@ int hvs_search_rescore(hvs_index *idx, const float *d_q, const float *d_qinv, in
         std::vector<int32_t> redo2;
         int n_redo2 = 0;
         const int n_sub = (int)list.size();
-        HVS_TRY(rescore_pass(idx, sub_q, sub_inv, n_sub, fold, k, kc_long, group_filter, d_mask, thr, eps, row_begin, row_end, c_dist, c_pos,
+        HVS_TRY(rescore_pass(idx, sub_q, sub_inv, n_sub, fold, k, kc_long, group_filter, d_mask, thr, eps, eps_tail, row_begin, row_end, c_dist, c_pos,
                              c_cnt, d_redo, sub_d, sub_i, sub_c, redo2, &n_redo2));
         HVS_TRY(scatter_flagged());  // unproven answers travel too and are overwritten below
         std::vector<int32_t> still;

@@ -594,6 +594,7 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
     hipFree(idx->attrs);
     hipFree(idx->split);
     hipFree(idx->split_inv);
+    hipFree(idx->split_rel);
     for (auto &w : idx->ws) hipFree(w.ptr);
     if (idx->h_pin) hipHostFree(idx->h_pin);
     hipEventDestroy(idx->ev0);

@@ -72,6 +72,8 @@ struct hvs_index {
     void *split = nullptr;
     float *split_inv = nullptr;
     int64_t split_cap = 0, split_n = 0;
+    uint32_t *split_rel = nullptr;  // [1] float bits: largest |row - hi slab| / |row| over the rows of the copy (split_rows_kernel)
+    const float *q_rel = nullptr;   // the same per query row of the last search that split its queries (lives in workspace 4 until the next search)
     bool split_allowed = true;  // hvs_index_search_copy(idx, 0): never build the copy (the table keeps its own size in HBM)
     bool split_failed = false;  // device memory did not allow the copy (cleared by hvs_index_compact and by an explicit hvs_index_prepare)
     std::string split_why;      // ... and why, for hvs_index_prepare's caller
@@ -139,7 +141,7 @@ int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_
 int hvs_noalloc_setup(int device);  // hvs_scan.hip: address of the scratch array of hvs_search_noalloc on `device` (current)
 
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,
-                   void *dst, float *dst_inv);
+                   void *dst, float *dst_inv, float *dst_rel, uint32_t *dst_rel_max);
 int hvs_split_ensure(hvs_index *idx, bool *ok);
 static inline void hvs_split_invalidate(hvs_index *idx, int64_t from_row) {
     if (from_row < idx->split_n) idx->split_n = from_row < 0 ? 0 : from_row;

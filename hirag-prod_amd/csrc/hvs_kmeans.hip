@@ -262,7 +262,9 @@ struct PickParams {
     int ldc;
     const float *c_norm;    // [K] |c|^2
     const float *cmax;      // [1] largest |c|
-    float eps2;             // 2 * (bound of the hi-slab dot product relative to |x| |c|)
+    float eps2;             // 2 * (bound of the hi-slab dot product relative to |x| |c|) for any operands
+    float eps_tail;         // the part of that bound that does not come from rounding the operands to fp16
+    const uint32_t *x_rel_max, *c_rel_max;  // [1] each, float bits: largest |v - hi slab| / |v| over the rows / the centroids
     const uint32_t *deleted;
     int32_t *assign;        // [n]
     uint32_t *flag_list;    // rows that need every product: [n] positions, any order
@@ -273,6 +275,8 @@ struct PickParams {
 template <int R> __global__ __launch_bounds__(256) void kmeans_pick_kernel(PickParams q) {
     const int lane = threadIdx.x & 63;
     const float cmax = *q.cmax;
+    const float rx = __uint_as_float(*q.x_rel_max), rc = __uint_as_float(*q.c_rel_max);
+    const float eps2 = fminf(q.eps2, 2.0f * (rx + rc * (1.0f + rx) + q.eps_tail));  // x.(c - ch) + (x - xh).ch by Cauchy-Schwarz
     const int nv = 2 * q.CT;
     for (int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6); row < q.n; row += (int64_t)gridDim.x * 4) {
         if (q.deleted && ((q.deleted[row >> 5] >> (row & 31)) & 1u)) {
@@ -282,7 +286,7 @@ template <int R> __global__ __launch_bounds__(256) void kmeans_pick_kernel(PickP
         float v[R], lo[R];
         const float inv = q.x_inv[row];
         const float xn = inv < __builtin_inff() ? 1.0f / inv : 0.0f;  // a zero row: every value is |c|^2 exactly
-        const float eb = q.eps2 * xn * cmax * 1.0001f;
+        const float eb = eps2 * xn * cmax * 1.0001f;
         float hi_min = __builtin_inff();
 #pragma unroll
         for (int e = 0; e < R; e++) {
@@ -469,7 +473,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
     const size_t ones_off = cis_off + (split ? up((size_t)K * 4) : 0);
     const size_t raw_off = ones_off + (split ? up((size_t)K * 4) : 0);
     const size_t raw_bytes = on_device ? 0 : (size_t)K * dim * 4;
-    const size_t ls_off = up(raw_off + raw_bytes);
+    const size_t rel_off = up(raw_off + raw_bytes);  // [1] largest |c - hi slab| / |c| of the split centroids (float bits)
+    const size_t ls_off = rel_off + 256;
     void *ws0 = nullptr;
     HVS_TRY(hvs_ws_get(idx, 0, ls_off + 4096 * 4, &ws0));
     const float *src = centroids;
@@ -493,7 +498,8 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         fill_ones_kernel<<<(K + 255) / 256, 256, 0, st>>>(ones, K);
         HVS_HIP(hipGetLastError());
         // "inverse norm" 1 in, 1 / scale out
-        HVS_TRY(hvs_split_rows(st, c_pad, ones, 0, K, ldc, ldc, ld16, (char *)ws0 + csplit_off, c_is));
+        HVS_HIP(hipMemsetAsync((char *)ws0 + rel_off, 0, 4, st));
+        HVS_TRY(hvs_split_rows(st, c_pad, ones, 0, K, ldc, ldc, ld16, (char *)ws0 + csplit_off, c_is, nullptr, (uint32_t *)((char *)ws0 + rel_off)));
         p.C = (char *)ws0 + csplit_off;
         p.ldc_bytes = ld16 * 4;
         p.c_iscale = c_is;
@@ -567,8 +573,12 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         q.ldc = ldc;
         q.c_norm = c_norm;
         q.cmax = cmax;
-        // |x.c - xh.ch / scales| <= (2^-10 (1 + 2^-10) + n 2^-24 [fp32 accumulation of exact products]) |x| |c|, twice that on |c|^2 - 2 x.c
-        q.eps2 = 2.0f * (9.78e-4f + (float)ld16 * 6.0e-8f + 1e-6f);
+        // |x.c - xh.ch / scales| <= (2^-10 (1 + 2^-10) + n 2^-24 [fp32 accumulation of exact products]) |x| |c|, twice that on |c|^2 - 2 x.c;
+        // the kernel replaces the first term by what split_rows_kernel measured on these rows and centroids where that is less
+        q.eps_tail = (float)ld16 * 6.0e-8f + 1e-6f;
+        q.eps2 = 2.0f * (9.78e-4f + q.eps_tail);
+        q.x_rel_max = idx->split_rel;
+        q.c_rel_max = (const uint32_t *)((char *)ws0 + rel_off);
         q.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
         q.assign = d_assign;
         q.flag_list = flag_list;

@@ -26,9 +26,15 @@ __device__ __forceinline__ float split_scale(float m, int *exp_out) {
 }
 
 // One wave per row.  src: fp32 rows of pitch ld_src floats (columns >= cols are ignored); dst: [n, 2 ld16] halves.
+// dst_rel (may be null): [n] |a s - hi| / |a s| of every row, the relative distance between a row and its hi slab
+// alone, rounded up; dst_rel_max (may be null): raised to the largest of them (float bits; the values are not
+// negative, so their order is the order of their bits).  A product over hi slabs alone errs by at most
+// rel_x + rel_q (1 + rel_x) of |q| |x| (Cauchy-Schwarz on q.(x - xh) + (q - qh).xh), which for rows that are not
+// built to sit at rounding midpoints is less than half of the 2^-10 the rounding unit alone guarantees.
 __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict__ src, const float *__restrict__ src_inv, int64_t first,
                                                          int64_t n, int cols, int ld_src, int ld16, __half *__restrict__ dst,
-                                                         float *__restrict__ dst_inv) {
+                                                         float *__restrict__ dst_inv, float *__restrict__ dst_rel,
+                                                         uint32_t *__restrict__ dst_rel_max) {
     const int lane = threadIdx.x & 63;
     const int64_t r = first + blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= first + n) return;
@@ -42,6 +48,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
     int ex;
     const float s = split_scale(m, &ex);
     __half *hi = dst + (size_t)r * 2 * ld16, *lo = hi + ld16;
+    float se = 0.0f, sx = 0.0f;  // sums of (a s - hi)^2 and (a s)^2
     for (int c = lane * 4; c < ld16; c += 256) {
         float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (c < cols) v = *reinterpret_cast<const float4 *>(a + c);
@@ -50,20 +57,37 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             h[i] = __float2half_rn(e[i]);
-            l[i] = __float2half_rn(e[i] - __half2float(h[i]));
+            const float d = e[i] - __half2float(h[i]);
+            l[i] = __float2half_rn(d);
+            se = fmaf(d, d, se);
+            sx = fmaf(e[i], e[i], sx);
         }
         *reinterpret_cast<uint2 *>(hi + c) = *reinterpret_cast<const uint2 *>(h);
         *reinterpret_cast<uint2 *>(lo + c) = *reinterpret_cast<const uint2 *>(l);
+    }
+    if (dst_rel || dst_rel_max) {
+        for (int off = 32; off > 0; off >>= 1) {
+            se += __shfl_xor(se, off);
+            sx += __shfl_xor(sx, off);
+        }
+        // both sums carry a relative rounding error below cols 2^-24 each; 1.001 covers it up to a million columns'
+        // worth of it and the rounding of the root.  A zero row, or one that holds a NaN or an infinity, has no score.
+        float rel = 0.0f;
+        if (sx > 0.0f && sx < __builtin_inff() && se == se) rel = sqrtf(se / sx) * 1.001f;
+        if (lane == 0) {
+            if (dst_rel) dst_rel[r - first] = rel;
+            if (dst_rel_max) atomicMax(dst_rel_max, __float_as_uint(rel));
+        }
     }
     if (lane == 0) dst_inv[r] = ldexpf(src_inv[r], -ex);
 }
 
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,
-                   void *dst, float *dst_inv) {
+                   void *dst, float *dst_inv, float *dst_rel, uint32_t *dst_rel_max) {
     if (n <= 0) return 0;
     const int64_t blocks = (n + 3) / 4;
     HVS_REQUIRE(blocks <= 0x7FFFFFFFll, "hvs_split_rows: too many rows for one launch");
-    split_rows_kernel<<<(int)blocks, 256, 0, st>>>(src, src_inv, first, n, cols, ld_src, ld16, (__half *)dst, dst_inv);
+    split_rows_kernel<<<(int)blocks, 256, 0, st>>>(src, src_inv, first, n, cols, ld_src, ld16, (__half *)dst, dst_inv, dst_rel, dst_rel_max);
     HVS_HIP(hipGetLastError());
     return 0;
 }
@@ -119,9 +143,14 @@ int hvs_split_ensure(hvs_index *idx, bool *ok) {
         idx->split_cap = cap;
         idx->split_n = keep;
     }
+    if (!idx->split_rel) {  // largest relative distance between a row and its hi slab; only ever raised
+        HVS_HIP(hipMalloc((void **)&idx->split_rel, 256));
+        HVS_HIP(hipMemsetAsync(idx->split_rel, 0, 256, idx->stream));
+    }
+    if (idx->split_n == 0) HVS_HIP(hipMemsetAsync(idx->split_rel, 0, 4, idx->stream));  // every row is examined again
     if (idx->split_n < idx->n) {
         HVS_TRY(hvs_split_rows(idx->stream, (const float *)idx->rows, idx->inv_norm, idx->split_n, idx->n - idx->split_n, idx->ld, idx->ld,
-                               ld16, idx->split, idx->split_inv));
+                               ld16, idx->split, idx->split_inv, nullptr, idx->split_rel));
         idx->split_n = idx->n;
     }
     *ok = true;

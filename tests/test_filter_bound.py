@@ -88,3 +88,53 @@ def test_kmeans_value_bound_follows():
     possible = lo <= hi.min(axis=1, keepdims=True)
     best = exact.argmin(axis=1)
     assert np.all(possible[np.arange(len(x)), best])
+
+
+def measured_rel(a):
+    """|a s - hi| / |a s| per row, the quantity split_rows_kernel hands to the filter passes"""
+    hi, s = split_hi(a)
+    scaled = np.asarray(a, dtype=np.float32).astype(np.float64) * s[:, None]
+    n = np.linalg.norm(scaled, axis=1)
+    return np.where(n > 0, np.linalg.norm(scaled - hi, axis=1) / np.maximum(n, 1e-300), 0.0)
+
+
+def check_measured(q, x):
+    """|q.x - qh.xh / scales| <= (rel_x + rel_q (1 + rel_x)) |q| |x|: Cauchy-Schwarz on q.(x - xh) + (q - qh).xh"""
+    qh, sq = split_hi(q)
+    xh, sx = split_hi(x)
+    exact = q.astype(np.float64) @ x.astype(np.float64).T
+    approx = (qh @ xh.T) / (sq[:, None] * sx[None, :])
+    qn = np.linalg.norm(q.astype(np.float64), axis=1)
+    xn = np.linalg.norm(x.astype(np.float64), axis=1)
+    rq, rx = measured_rel(q), measured_rel(x)
+    lim = (rx[None, :] + rq[:, None] * (1.0 + rx[None, :])) * qn[:, None] * xn[None, :]
+    err = np.abs(exact - approx)
+    assert np.all(err <= lim * (1 + 1e-9) + 1e-300), float((err / np.maximum(lim, 1e-300)).max())
+    assert np.all(rx <= BOUND / 2 * (1 + 1e-6)) and np.all(rq <= BOUND / 2 * (1 + 1e-6))  # never looser than the rounding unit's
+    return float((err / np.maximum(lim, 1e-300)).max()), float(rx.max())
+
+
+@pytest.mark.parametrize("dim", [8, 96, 768, 1536])
+def test_measured_bound_holds_and_is_tighter_on_random_rows(dim):
+    rng = np.random.default_rng(100 + dim)
+    q = rng.standard_normal((16, dim)).astype(np.float32)
+    x = rng.standard_normal((64, dim)).astype(np.float32)
+    x[:16] *= np.float32(3e4)
+    x[16:32] *= np.float32(1e-6)
+    x[32:40] *= (10.0 ** rng.uniform(-3, 3, (8, dim))).astype(np.float32)
+    worst, rx = check_measured(q, x)
+    assert worst <= 1.0
+    if dim >= 768:
+        assert rx < 0.6 * BOUND / 2  # rows of a normal distribution sit at about half of the rounding unit's bound
+
+
+def test_measured_bound_when_every_rounding_error_lines_up():
+    dim = 512
+    j = np.arange(1024 + 1, 1024 + 1 + dim)
+    v = (8.0 * j + 3.99).astype(np.float32)
+    v[0] = np.float32(2.0 ** 14 - 8)
+    ones = np.full((1, dim), 8.0 * 1500, dtype=np.float32)  # on the grid: no error of its own, and parallel to the row's error
+    worst, _ = check_measured(ones, v[None, :])
+    assert 0.9 < worst <= 1.0  # the bound is attained, not exceeded
+    worst, _ = check_measured(v[None, :], v[None, ::-1].copy())
+    assert 0.5 < worst <= 1.0

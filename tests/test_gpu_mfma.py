@@ -476,6 +476,57 @@ def test_filter_route_on_ladders_of_close_rows(hvs):
     idx.close()
 
 
+def _rows_at_rounding_midpoints(rng, n, d, down):
+    """Positive rows whose scaled elements lie 3.99 above (down[i]: rounded down by fp16) or 3.99 below (rounded up) a
+    point of the fp16 grid of [2^13, 2^14) (spacing 8); one exact element pins every row's scale at 1."""
+    j = rng.integers(1024, 2047, (n, d))
+    x = 8.0 * j + np.where(down[:, None], 3.99, -3.99)
+    x[:, 0] = 2.0 ** 14 - 8
+    return x.astype(np.float32)
+
+
+def test_filter_bound_when_rounding_errors_line_up(hvs):
+    """The filter passes bound the error of a hi-slab product by how far THESE rows and queries lie from their hi slabs
+    (measured when they are split), which for ordinary data is well under the 2^-10 of the rounding unit.  Rows built to
+    use that bound up: every element of a row rounds the same way by almost half a grid step, half of the rows up and
+    half down, against all-positive queries -- the hi-slab scores of the two halves are off by 3e-4 in opposite
+    directions while the rows lie about 1e-3 apart, so the approximate order is wrong everywhere.  Exact answers
+    expected from the searches and from the k-means assignment (whose centroids are such rows too)."""
+    rng = np.random.default_rng(2718)
+    n, d = 6000, 256
+    down = rng.random(n) < 0.5
+    rows = _rows_at_rounding_midpoints(rng, n, d, down)
+    q_exact = (8.0 * rng.integers(1024, 2047, (24, d))).astype(np.float32)  # on the grid: the queries' own error is zero
+    q_mid = _rows_at_rounding_midpoints(rng, 24, d, rng.random(24) < 0.5)    # ... and queries that round like the rows
+    q = np.concatenate([q_exact, q_mid])
+    dm = parity.distance_matrix(rows, q, "f32")
+    # the construction does what it says: hi slabs alone misplace the two halves by about 3e-4 against each other
+    hi = rows.astype(np.float16).astype(np.float64)
+    approx = 1.0 - (q_exact.astype(np.float64) @ hi.T) / (np.linalg.norm(q_exact.astype(np.float64), axis=1)[:, None] * np.linalg.norm(rows.astype(np.float64), axis=1)[None, :])
+    shift = approx - dm[:24]
+    assert shift[:, down].min() > 2.5e-4 and shift[:, ~down].max() < -2.5e-4
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    for k in (1, 10, 32):
+        for algo in ("mfma", "auto"):
+            dist, ids, cnt = idx.search(q, k=k, algo=algo)
+            for i in range(q.shape[0]):
+                parity.check_topk(dist[i], ids[i], cnt[i], dm[i], k, label=f"lined-up k={k} {algo} q={i}")
+    thr = float(np.sort(dm[3])[5] + 1e-6)
+    dist, ids, cnt = idx.search(q, k=10, max_distance=thr, algo="mfma")
+    for i in range(q.shape[0]):
+        parity.check_topk(dist[i], ids[i], cnt[i], dm[i], 10, threshold=thr, label=f"lined-up thr q={i}")
+    # k-means: 128 of the rows as centroids
+    c = rows[rng.choice(n, 128, replace=False)].copy()
+    assign, _, counts = idx.kmeans_assign(c)
+    exp, margin = kmeans_oracle.assign(rows, c)
+    safe = margin > 1e-5 * np.sum(rows.astype(np.float64) ** 2, axis=1)
+    assert safe.mean() > 0.9
+    np.testing.assert_array_equal(assign[safe], exp[safe])
+    assert int(counts.sum()) == n
+    idx.close()
+
+
 def test_kmeans_on_an_empty_index_returns_zero_sums(hvs):
     """A rank whose shard is empty must feed zeros into the centroid all-reduce."""
     import torch
