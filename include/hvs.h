@@ -41,7 +41,8 @@ enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
  * 16-bit pipe over a split copy of the rows (two fp16 slabs per row, three products, fp32-grade
  * scores; the copy doubles the table's device memory and is built on first use) and falls back to the
  * fp32 MFMA kernel when memory does not allow the copy.  For k <= 128 the split copy is first used as a
- * filter: one product over the hi slabs bounds every score to within 1.1e-3, the 4 k (at most 256) best candidates per
+ * filter: one product over the hi slabs bounds every score to within 1.1e-3 (less where the rows and queries at hand
+ * lie closer to their hi slabs, which is measured when they are split), the 4 k (at most 256) best candidates per
  * query are scored again from the fp32 rows in fp32, a query whose k-th exact score does not clear the bound of the
  * rows left out goes through the filter once more with 256 candidates, and what that leaves unproven is searched
  * again in full -- the exact top-k either way.  MFMA_SPLIT: the three products for every score, no filter.
