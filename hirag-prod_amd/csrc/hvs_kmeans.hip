@@ -271,82 +271,98 @@ struct PickParams {
     uint32_t *flag_count;
 };
 
-// One wave per row.  Value j of the row (j = 2 * tile + which) sits in lane j & 63 of register j >> 6.
+// A block takes PICK_ROWS rows at a time: the 2 CT values of each are read tile by tile (rows on lanes: the layout the
+// assignment kernel writes, 512 contiguous bytes per wave and tile) into LDS, then one wave per row goes over them with
+// value j of the row (j = 2 * tile + which) in lane j & 63 of register j >> 6.
+#define PICK_ROWS 64
 template <int R> __global__ __launch_bounds__(256) void kmeans_pick_kernel(PickParams q) {
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) float pick_vals[];  // [PICK_ROWS][2 CT + 2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float cmax = *q.cmax;
     const float rx = __uint_as_float(*q.x_rel_max), rc = __uint_as_float(*q.c_rel_max);
     const float eps2 = fminf(q.eps2, 2.0f * (rx + rc * (1.0f + rx) + q.eps_tail));  // x.(c - ch) + (x - xh).ch by Cauchy-Schwarz
-    const int nv = 2 * q.CT;
-    for (int64_t row = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6); row < q.n; row += (int64_t)gridDim.x * 4) {
-        if (q.deleted && ((q.deleted[row >> 5] >> (row & 31)) & 1u)) {
-            if (lane == 0) q.assign[row] = -1;
-            continue;
+    const int nv = 2 * q.CT, pitch = nv + 2;
+    for (int64_t row0 = blockIdx.x * (int64_t)PICK_ROWS; row0 < q.n; row0 += (int64_t)gridDim.x * PICK_ROWS) {
+        for (int i = threadIdx.x; i < q.CT * PICK_ROWS; i += 256) {
+            const int ct = i / PICK_ROWS, r = i % PICK_ROWS;
+            if (row0 + r < q.n)
+                *reinterpret_cast<float2 *>(pick_vals + r * pitch + 2 * ct) =
+                    *reinterpret_cast<const float2 *>(q.best + ((size_t)ct * q.n + row0 + r) * 2);
         }
-        float v[R], lo[R];
-        const float inv = q.x_inv[row];
-        const float xn = inv < __builtin_inff() ? 1.0f / inv : 0.0f;  // a zero row: every value is |c|^2 exactly
-        const float eb = eps2 * xn * cmax * 1.0001f;
-        float hi_min = __builtin_inff();
-#pragma unroll
-        for (int e = 0; e < R; e++) {
-            const int j = e * 64 + lane;
-            v[e] = j < nv ? q.best[((size_t)(j >> 1) * q.n + row) * 2 + (j & 1)] : __builtin_nanf("");
-            const float err = eb + fabsf(v[e]) * 3.1e-5f;  // + the truncated low byte (2^-15 relative)
-            lo[e] = v[e] - err;
-            hi_min = fminf(hi_min, v[e] + err);  // fminf drops NaN
-        }
-        for (int off = 32; off > 0; off >>= 1) hi_min = fminf(hi_min, __shfl_xor(hi_min, off));
-        uint64_t m[R];
-        int count = 0;
-        bool second = false;
-#pragma unroll
-        for (int e = 0; e < R; e++) {
-            m[e] = __ballot(lo[e] <= hi_min);  // false for NaN
-            count += __popcll(m[e]);
-            second |= (m[e] & 0xAAAAAAAAAAAAAAAAull) != 0;  // odd j: a tile's second best
-        }
-        if (count == 0 || second) {  // no finite value at all, or a tile that may hide a third contender
-            if (lane == 0) {
-                q.flag_list[atomicAdd(q.flag_count, 1u)] = (uint32_t)row;  // integer: the list's order does not reach the result
-                q.assign[row] = -1;
+        __syncthreads();
+        for (int r = wave; r < PICK_ROWS; r += 4) {
+            const int64_t row = row0 + r;
+            if (row >= q.n) break;
+            if (q.deleted && ((q.deleted[row >> 5] >> (row & 31)) & 1u)) {
+                if (lane == 0) q.assign[row] = -1;
+                continue;
             }
-            continue;
-        }
-        uint64_t best_key = HVS_KEY_EMPTY;
+            float v[R], lo[R];
+            const float inv = q.x_inv[row];
+            const float xn = inv < __builtin_inff() ? 1.0f / inv : 0.0f;  // a zero row: every value is |c|^2 exactly
+            const float eb = eps2 * xn * cmax * 1.0001f;
+            float hi_min = __builtin_inff();
 #pragma unroll
-        for (int e = 0; e < R; e++) {
-            uint64_t pending = m[e];
-            while (pending) {
-                const int src = __ffsll((unsigned long long)pending) - 1;
-                pending &= pending - 1;
-                const uint32_t bits = __builtin_amdgcn_readlane(__float_as_uint(v[e]), src);
-                const uint32_t c = (uint32_t)(((e * 64 + src) >> 1) * q.bm) + (bits & 0xFFu);
-                if (count == 1) {
-                    best_key = c;
-                    break;
+            for (int e = 0; e < R; e++) {
+                const int j = e * 64 + lane;
+                v[e] = j < nv ? pick_vals[r * pitch + j] : __builtin_nanf("");
+                const float err = eb + fabsf(v[e]) * 3.1e-5f;  // + the truncated low byte (2^-15 relative)
+                lo[e] = v[e] - err;
+                hi_min = fminf(hi_min, v[e] + err);  // fminf drops NaN
+            }
+            for (int off = 32; off > 0; off >>= 1) hi_min = fminf(hi_min, __shfl_xor(hi_min, off));
+            uint64_t m[R];
+            int count = 0;
+            bool second = false;
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                m[e] = __ballot(lo[e] <= hi_min);  // false for NaN
+                count += __popcll(m[e]);
+                second |= (m[e] & 0xAAAAAAAAAAAAAAAAull) != 0;  // odd j: a tile's second best
+            }
+            if (count == 0 || second) {  // no finite value at all, or a tile that may hide a third contender
+                if (lane == 0) {
+                    q.flag_list[atomicAdd(q.flag_count, 1u)] = (uint32_t)row;  // integer: the list's order does not reach the result
+                    q.assign[row] = -1;
                 }
-                // several tile-bests within the bound of each other: exact fp32 values decide
-                const float *x = q.rows + (size_t)row * q.ld, *cc = q.c_pad + (size_t)c * q.ldc;
-                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-                for (int i = lane * 4; i < q.ld; i += 256) {  // ld is a multiple of 4, pad columns are zero on both sides
-                    const float4 a = *reinterpret_cast<const float4 *>(x + i);
-                    const float4 b = *reinterpret_cast<const float4 *>(cc + i);
-                    s0 = fmaf(a.x, b.x, s0);
-                    s1 = fmaf(a.y, b.y, s1);
-                    s2 = fmaf(a.z, b.z, s2);
-                    s3 = fmaf(a.w, b.w, s3);
-                }
-                float dot = (s0 + s1) + (s2 + s3);
-                for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-                const float val = fmaf(-2.0f, dot, q.c_norm[c]);
-                if (val == val) {
-                    const uint64_t key = hvs_make_key(hvs_ord(val), c);  // ties go to the lower centroid
-                    best_key = key < best_key ? key : best_key;
+                continue;
+            }
+            uint64_t best_key = HVS_KEY_EMPTY;
+#pragma unroll
+            for (int e = 0; e < R; e++) {
+                uint64_t pending = m[e];
+                while (pending) {
+                    const int src = __ffsll((unsigned long long)pending) - 1;
+                    pending &= pending - 1;
+                    const uint32_t bits = __builtin_amdgcn_readlane(__float_as_uint(v[e]), src);
+                    const uint32_t c = (uint32_t)(((e * 64 + src) >> 1) * q.bm) + (bits & 0xFFu);
+                    if (count == 1) {
+                        best_key = c;
+                        break;
+                    }
+                    // several tile-bests within the bound of each other: exact fp32 values decide
+                    const float *x = q.rows + (size_t)row * q.ld, *cc = q.c_pad + (size_t)c * q.ldc;
+                    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                    for (int i = lane * 4; i < q.ld; i += 256) {  // ld is a multiple of 4, pad columns are zero on both sides
+                        const float4 a = *reinterpret_cast<const float4 *>(x + i);
+                        const float4 b = *reinterpret_cast<const float4 *>(cc + i);
+                        s0 = fmaf(a.x, b.x, s0);
+                        s1 = fmaf(a.y, b.y, s1);
+                        s2 = fmaf(a.z, b.z, s2);
+                        s3 = fmaf(a.w, b.w, s3);
+                    }
+                    float dot = (s0 + s1) + (s2 + s3);
+                    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+                    const float val = fmaf(-2.0f, dot, q.c_norm[c]);
+                    if (val == val) {
+                        const uint64_t key = hvs_make_key(hvs_ord(val), c);  // ties go to the lower centroid
+                        best_key = key < best_key ? key : best_key;
+                    }
                 }
             }
+            if (lane == 0) q.assign[row] = best_key == HVS_KEY_EMPTY ? -1 : (int32_t)(uint32_t)best_key;
         }
-        if (lane == 0) q.assign[row] = best_key == HVS_KEY_EMPTY ? -1 : (int32_t)(uint32_t)best_key;
+        __syncthreads();  // the values are overwritten by the next group of rows
     }
 }
 
@@ -583,12 +599,16 @@ extern "C" int hvs_kmeans_assign(hvs_index *idx, const float *centroids, int n_c
         q.assign = d_assign;
         q.flag_list = flag_list;
         q.flag_count = flag_count;
-        int pg = (int)((n + 3) / 4);
-        if (pg > 256 * 64) pg = 256 * 64;
+        int pg = (int)((n + PICK_ROWS - 1) / PICK_ROWS);
+        if (pg > 256 * 16) pg = 256 * 16;
         const int nv = 2 * p1.CT;
-        if (nv <= 64) kmeans_pick_kernel<1><<<pg, 256, 0, st>>>(q);
-        else if (nv <= 128) kmeans_pick_kernel<2><<<pg, 256, 0, st>>>(q);
-        else kmeans_pick_kernel<4><<<pg, 256, 0, st>>>(q);
+        const size_t pick_lds = (size_t)PICK_ROWS * (nv + 2) * 4;  // at most 64 x 258 floats
+        if (nv <= 64) kmeans_pick_kernel<1><<<pg, 256, pick_lds, st>>>(q);
+        else if (nv <= 128) kmeans_pick_kernel<2><<<pg, 256, pick_lds, st>>>(q);
+        else {
+            HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&kmeans_pick_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pick_lds));
+            kmeans_pick_kernel<4><<<pg, 256, pick_lds, st>>>(q);
+        }
         HVS_HIP(hipGetLastError());
         uint32_t n_flag = 0;
         HVS_HIP(hipMemcpyAsync(&n_flag, flag_count, 4, hipMemcpyDeviceToHost, st));

@@ -15,13 +15,29 @@
 #define UPD_THREADS 256
 #define UPD_SLICE_ROWS 1024  // rows added up by one block
 
-__global__ void upd_keys_kernel(const int32_t *__restrict__ assign, int64_t n, uint32_t *__restrict__ keys,
-                                uint32_t *__restrict__ vals, uint32_t *__restrict__ hist) {
+// hist[key] counts the rows per key.  A block counts its rows in LDS first (UPD_LDS_BUCKETS counters, as many as a
+// block's LDS holds with room to spare) and adds its non-zero counters to the global ones at the end: one global atomic
+// per row, all aimed at a few thousand addresses, took 8.5 ms for 10M rows; this takes a fraction of a millisecond.
+#define UPD_LDS_BUCKETS 16384
+__global__ __launch_bounds__(1024) void upd_keys_kernel(const int32_t *__restrict__ assign, int64_t n, uint32_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ vals, uint32_t *__restrict__ hist, int buckets) {
+    __shared__ uint32_t local[UPD_LDS_BUCKETS];
+    const bool in_lds = buckets <= UPD_LDS_BUCKETS;
+    if (in_lds) {
+        for (int b = threadIdx.x; b < buckets; b += blockDim.x) local[b] = 0;
+        __syncthreads();
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t key = (uint32_t)(assign[i] + 1);  // 0 = row without an assignment (deleted)
         keys[i] = key;
         vals[i] = (uint32_t)i;
-        atomicAdd(&hist[key], 1u);  // integer: order-independent
+        if (in_lds) atomicAdd(&local[key], 1u);  // integer: order-independent
+        else atomicAdd(&hist[key], 1u);
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < buckets; b += blockDim.x)
+            if (local[b]) atomicAdd(&hist[b], local[b]);
     }
 }
 
@@ -181,9 +197,9 @@ int hvs_kmeans_update(hvs_index *idx, const int32_t *d_assign, int64_t n, int K,
     float *partial = (float *)(w + o_partial);
 
     HVS_HIP(hipMemsetAsync(hist, 0, (size_t)buckets * 4, st));
-    int g = (int)((n + 255) / 256);
-    if (g > 256 * 16) g = 256 * 16;
-    upd_keys_kernel<<<g, 256, 0, st>>>(d_assign, n, keys_in, vals_in, hist);
+    int g = (int)((n + 1023) / 1024);
+    if (g > 512) g = 512;  // two blocks per CU: each adds its counters to the global ones once
+    upd_keys_kernel<<<g, 1024, 0, st>>>(d_assign, n, keys_in, vals_in, hist, buckets);
     upd_scan_kernel<<<1, 1024, 0, st>>>(hist, buckets, start, slice_start, (long long *)d_counts);
     HVS_HIP(hipGetLastError());
     HVS_HIP(rocprim::radix_sort_pairs(w + o_temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, st));
