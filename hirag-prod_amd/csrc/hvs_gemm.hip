@@ -618,10 +618,13 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(srcA.rsrc, (lds_void *)(stage + BM * KB + (T::A_THREADS * i + wave_a * 64) * 16), 16,
                                                          srcA.voff[i], off_a2, 0, 0);
         }
+        // the corpus passes through once and is read by this block alone: non-temporal (aux bit 1), so that it does not push
+        // the query tile out of L2 nor wait for room there -- a plain streaming read of this shape reaches 6.2 TB/s, a
+        // non-temporal one 7.0 (tools/dma_bw.hip)
 #pragma unroll
         for (int i = 0; i < T::NB; i++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srcB.rsrc, (lds_void *)(stage + X_IMAGE + (T::GT * i + wave * 64) * 16), 16, srcB.voff[i],
-                                                     off_b, 0, 0);
+                                                     off_b, 0, 2);
     };
 
     // fetch cursor: the step whose fetch is issued next (runs NS - 1 steps ahead of the compute cursor)

@@ -81,6 +81,13 @@ __global__ __launch_bounds__(1024) void upd_scan_kernel(const uint32_t *__restri
     }
 }
 
+// 16 bytes of a row, read once by the whole pass: non-temporal, so that the 61 GB of rows stream past L2 instead of through it
+typedef float upd_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_row4(const float4 *p) {
+    const upd_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const upd_f32x4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // Block b adds the rows of one slice, in order, into partial[b][ld]; thread t owns the 16-byte column
 // groups t, t + 256, ... .  Blocks beyond the last slice do nothing.
 template <int COLS4>
@@ -113,10 +120,10 @@ __global__ __launch_bounds__(UPD_THREADS) void upd_sum_kernel(const float *__res
         for (int j = 0; j < COLS4; j++) {
             const int c = threadIdx.x + j * UPD_THREADS;
             const bool in = c < ld4;
-            v[0][j] = in ? X4[(size_t)r0 * ld4 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            v[1][j] = in ? X4[(size_t)r1 * ld4 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            v[2][j] = in ? X4[(size_t)r2 * ld4 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            v[3][j] = in ? X4[(size_t)r3 * ld4 + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            v[0][j] = in ? load_row4(X4 + (size_t)r0 * ld4 + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            v[1][j] = in ? load_row4(X4 + (size_t)r1 * ld4 + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            v[2][j] = in ? load_row4(X4 + (size_t)r2 * ld4 + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            v[3][j] = in ? load_row4(X4 + (size_t)r3 * ld4 + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(UPD_THREADS) void upd_sum_kernel(const float *__res
         for (int j = 0; j < COLS4; j++) {
             const int c = threadIdx.x + j * UPD_THREADS;
             if (c < ld4) {
-                const float4 x = X4[(size_t)r0 * ld4 + c];
+                const float4 x = load_row4(X4 + (size_t)r0 * ld4 + c);
                 acc[j].x += x.x;
                 acc[j].y += x.y;
                 acc[j].z += x.z;
