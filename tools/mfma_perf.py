@@ -36,10 +36,10 @@ if __name__ == "__main__":
         idx.search(q, k=a.k, algo="mfma")
     ms, n = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)
     mm, nm = idx.profile_get(_lib.HVS_PROF_MERGE)
-    per = ms / n
+    per = ms / a.iters  # every launch of a search counts (a sample pass ahead of the main one, a second list length, ...)
     flops = 2.0 * a.nq * a.rows * a.dim
     print(f"mfma search {a.dtype} rows={a.rows} dim={a.dim} nq={a.nq} k={a.k}: {per:.2f} ms/batch  {flops / per / 1e9:.1f} TFLOP/s "
-          f"({flops / per / 1e9 / peak * 100:.1f}% of {peak})  merge {mm / nm:.3f} ms  -> {a.nq / (per + mm / nm) * 1e3:.0f} QPS", flush=True)
+          f"({flops / per / 1e9 / peak * 100:.1f}% of {peak}; {n / a.iters:g} launches per search)  merge {mm / a.iters:.3f} ms  -> {a.nq / (per + mm / a.iters) * 1e3:.0f} QPS", flush=True)
     if a.kmeans:
         c = torch.randn((a.kmeans, a.dim), device="cuda")
         idx.profile_reset()
