@@ -30,14 +30,15 @@ __global__ __launch_bounds__(512) void stream_kernel(const char *__restrict__ bu
     // contiguous window of the buffer; otherwise every block streams a contiguous part of its own
     const char *base = INTER ? buf : buf + (size_t)blockIdx.x * bytes_per_block;
     // a batch = 4 instructions of this wave = 4 KB; the block's 8 waves cover 32 KB per batch
-    const size_t batches = bytes_per_block / (32 * 1024);
+    const size_t batches = bytes_per_block / ((pitch < 0 ? 64 : 32) * 1024);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)base);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)base >> 32));
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(((uintptr_t)hi << 32) | lo), 0, INTER ? 0xFFFFFFFF : (int)bytes_per_block, 0x00020000);
     u32x4 acc = {0, 0, 0, 0};
     char *my_lds = smem + wave * (DEPTH * 4096);
     // strided pattern: batch b covers rows [8 w + 64 i, +8) of a 256-row tile at byte column (b % cols) * 128, tile b / cols
-    const int cols = pitch / 128;
+    const int cols = (pitch < 0 ? -pitch / 2 : pitch) / 128;  // negative pitch: only the first half of every row is read
+    pitch = pitch < 0 ? -pitch : pitch;
     auto offset = [&](size_t b, int i) -> uint32_t {
         if (MODE == 0 || MODE == 2) return (uint32_t)((INTER ? b * gridDim.x + blockIdx.x : b) * 32768 + (size_t)(wave * 4 + i) * 1024 + lane * 16);
         const size_t tile = INTER ? (b / cols) * gridDim.x + blockIdx.x : b / cols;
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(512) void stream_kernel(const char *__restrict__ bu
 }
 
 template <int MODE, int DEPTH, bool INTER = false, int NT = 0> static void run(const char *buf, size_t total, int pitch, uint32_t *sink, const char *what, int grid = 256) {
-    size_t per_block = total / grid / (256 * (size_t)pitch) * (256 * (size_t)pitch);  // whole tiles
+    const size_t apitch = pitch < 0 ? -pitch : pitch;
+    size_t per_block = total / grid / (256 * apitch) * (256 * apitch);  // whole tiles
     per_block = per_block / 32768 * 32768;
     const size_t lds = 8 * DEPTH * 4096;
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&stream_kernel<MODE, DEPTH, INTER, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -106,7 +108,8 @@ template <int MODE, int DEPTH, bool INTER = false, int NT = 0> static void run(c
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (it > 0 && ms < best) best = ms;
     }
-    printf("%-62s %s aux %2d depth %d grid %4d: %7.3f ms  %7.1f GB/s\n", what, INTER ? "round-robin" : "own part   ", NT, DEPTH, grid, best, per_block * (double)grid / best / 1e6);
+    printf("%-62s %s aux %2d depth %d grid %4d: %7.3f ms  %7.1f GB/s\n", what, INTER ? "round-robin" : "own part   ", NT, DEPTH, grid, best,
+           per_block * (double)grid / (pitch < 0 ? 2 : 1) / best / 1e6);
 }
 
 int main() {
@@ -139,6 +142,9 @@ int main() {
         run<1, 2, false, 2>(buf, total, pitch, sink, "LDS-DMA b128, 8 rows x 128 B per instruction (pitch 3072)", grid);
         run<2, 4, false, 2>(buf, total, pitch, sink, "global_load_dwordx4, 1 KB contiguous per instruction", grid);
     }
+    // the first 3072 bytes of rows of 6144 (the hi slabs of a split copy), GB/s of the bytes asked for
+    run<1, 2, false, 2>(buf, total, -6144, sink, "LDS-DMA b128, 8 rows x 128 B, first half of 6144-byte rows");
+    run<1, 2, false, 0>(buf, total, -6144, sink, "LDS-DMA b128, 8 rows x 128 B, first half of 6144-byte rows");
     // other cache-policy bits of the LDS-DMA instruction (bit 0 sc0, bit 1 nt, bit 4 sc1)
     run<1, 2, false, 1>(buf, total, pitch, sink, "LDS-DMA b128, 8 rows x 128 B per instruction (pitch 3072)");
     run<1, 2, false, 3>(buf, total, pitch, sink, "LDS-DMA b128, 8 rows x 128 B per instruction (pitch 3072)");
