@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 closing measurements on one MI355X (repo root): GPU tests, the probes whose numbers DESIGN.md quotes, and the
+# Closing measurements on one MI355X (repo root): GPU tests, the probes whose numbers the design notes quote, and the
 # bench.py run under the kernel tracer plus its fabric-byte passes.  Everything lands under gpurun_out/r2_final/.
 # Each step has its own time limit; a failing step ends the script.
 set -o pipefail
