@@ -406,6 +406,15 @@ template <class T> __device__ __forceinline__ BlockState block_state(char *smem,
     return b;
 }
 
+// The timing hooks of this kernel (HVS_DBG bits 4, 8, 512: branches in every k-step, five live 64-bit counters) cost
+// 2 % of every launch even when they are off (2M x 1536 x 4096 queries: f16 995 -> 1 015 TFLOP/s, fp32 176.8 -> 173.3 ms),
+// so they are compiled in only with -DHVS_KERNEL_HOOKS (make HOOKS=1); the host refuses HVS_DBG without them.
+#ifdef HVS_KERNEL_HOOKS
+#define HVS_HOOK(p) ((p).dbg)
+#else
+#define HVS_HOOK(p) 0
+#endif
+
 template <int DT, int FOLD, class T>
 __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
 
     int64_t tile = tile_lo;
     int ks = 0;
-    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (p.dbg & 512) ? clock64() : 0;
+    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (HVS_HOOK(p) & 512) ? clock64() : 0;
     for (int64_t g = 0; g < total_steps; g++) {
         const int cur = (int)(g & 1);
         // next step's coordinates; after the last step the current tile's step 0 is fetched again (harmless,
@@ -469,15 +478,15 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
                             next_off, wave);
         const bool tile_end = ks == p.nks - 1;
-        const bool prof = tile_end && (p.dbg & 512);
+        const bool prof = tile_end && (HVS_HOOK(p) & 512);
         unsigned long long c1 = 0, c2 = 0, c3 = 0;
         if (prof) c1 = clock64();
         if (tile_end) {
-            if (!(p.dbg & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+            if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
             zero_acc(acc);
         }
         if (prof) c2 = clock64();
-        if (!(p.dbg & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
+        if (!(HVS_HOOK(p) & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
         if (prof) c3 = clock64();
         if (tile_end) {
             compact_lists<FOLD, T>(p, b, wave, lane);
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         ks = nks_next;
         tile = ntile;
     }
-    if ((p.dbg & 512) && lane == 0) {
+    if ((HVS_HOOK(p) & 512) && lane == 0) {
         atomicAdd(&p.prof[0], pr_loop);
         atomicAdd(&p.prof[1], pr_epi);
         atomicAdd(&p.prof[2], pr_bar);
@@ -1104,6 +1113,9 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.cap = k > 128 ? CAND_MAX : CAND_SMALL;  // >= k + bn with room to let an array grow to 2 k between rankings: the survivors of one more tile always fit
     p.dbg = 0;
     if (const char *e = getenv("HVS_DBG")) p.dbg = stream ? 0 : atoi(e);
+#ifndef HVS_KERNEL_HOOKS
+    HVS_REQUIRE(p.dbg == 0, "HVS_DBG=%d: this libhvs.so was built without the kernel's timing hooks (make HOOKS=1 builds them in)", p.dbg);
+#endif
     p.QT = stream ? 1 : (nA + bm - 1) / bm;
 
     // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
