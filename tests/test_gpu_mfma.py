@@ -539,3 +539,20 @@ def test_kmeans_on_an_empty_index_returns_zero_sums(hvs):
     assign, sums, counts = idx.kmeans_assign(ct)
     assert int(sums.abs().sum().item()) == 0 and int(counts.sum().item()) == 0
     idx.close()
+
+
+def test_timing_hooks_are_refused_by_a_library_built_without_them(hvs, monkeypatch):
+    """HVS_DBG switches parts of the batched kernel off for timing experiments (wrong results); the library the tests
+    run against is built without those hooks and must say so instead of ignoring the variable."""
+    rng = np.random.default_rng(1)
+    idx = hvs.HvsIndex(64, "f16")
+    idx.add(rng.standard_normal((4096, 64)).astype(np.float32))
+    q = rng.standard_normal((200, 64)).astype(np.float32)
+    monkeypatch.setenv("HVS_DBG", "8")
+    monkeypatch.setenv("HVS_STREAM", "0")
+    with pytest.raises(hvs.HvsError, match="HOOKS=1"):
+        idx.search(q, k=5, algo="mfma")
+    monkeypatch.delenv("HVS_DBG")
+    dist, ids, cnt = idx.search(q, k=5, algo="mfma")
+    assert np.all(cnt == 5)
+    idx.close()
