@@ -455,62 +455,71 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
     }
     __syncthreads();
 
-    int64_t tile = tile_lo;
-    int ks = 0;
-    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (HVS_HOOK(p) & 512) ? clock64() : 0;
-    for (int64_t g = 0; g < total_steps; g++) {
-        const int cur = (int)(g & 1);
-        // next step's coordinates; after the last step the current tile's step 0 is fetched again (harmless,
-        // keeps the loop free of branches around the LDS-DMA instructions)
-        int nks_next = ks + 1;
-        int64_t ntile = tile;
-        if (nks_next == p.nks) { nks_next = 0; ntile = tile + 1; }
-        if (nks_next == 0 && g + 1 < total_steps) init_b(ntile);
-        if (ks == 0) load_row_meta<T>(p, tile, wn, lane, invn2);
-        if (ks == 0 && tid == 0 && p.lockstep != nullptr && members > 1)
+    // (A, X) byte offsets of k-step k inside a row.  Split operands run three slab pairs, (hi, hi), (hi, lo), (lo, hi), of
+    // split_steps steps each; plain operands are the first pair of a split that never ends
+    const int slab_steps = p.split_steps ? p.split_steps : 0x3fffffff;
+    auto step_off = [&](int k) {
+        const int slab = (k >= 2 * slab_steps ? 1 : 0) + (k >= slab_steps ? 1 : 0), w = k - slab * slab_steps;
+        return KOff{((slab == 2 ? slab_steps : 0) + w) * KB, ((slab == 1 ? slab_steps : 0) + w) * KB};
+    };
+    // A tile loop around a k loop without tile bookkeeping in it: the steps whose successor lies in the same tile run
+    // in the inner loop, the tile's last step (whose LDS-DMA fetches step 0 of the next tile) is written out after it.
+    int cur = 0;
+#ifdef HVS_KERNEL_HOOKS
+    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (p.dbg & 512) ? clock64() : 0;
+#endif
+    for (int64_t tile = tile_lo; tile < tile_hi; tile++) {
+        load_row_meta<T>(p, tile, wn, lane, invn2);
+        if (tid == 0 && p.lockstep != nullptr && members > 1)
             lockstep_arrive(step_counter, (unsigned int)(tile - tile_lo + 1), members, in_step);
-        KOff next_off = koff_plain(nks_next);
-        if (p.split_steps) {  // slab pairs (A, X) of the three products: (hi, hi), (hi, lo), (lo, hi)
-            const int slab = nks_next >= 2 * p.split_steps ? 2 : (nks_next >= p.split_steps ? 1 : 0), w = nks_next - slab * p.split_steps;
-            next_off.a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
-            next_off.b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
+        for (int ks = 0; ks + 1 < p.nks; ks++) {
+            compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
+                                step_off(ks + 1), wave);
+            if (!(HVS_HOOK(p) & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
+            cur ^= 1;
         }
-        compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES,
-                            next_off, wave);
-        const bool tile_end = ks == p.nks - 1;
-        const bool prof = tile_end && (HVS_HOOK(p) & 512);
+        // after the last tile its own step 0 is fetched again (harmless, keeps the step free of branches around the LDS-DMA)
+        if (tile + 1 < tile_hi) init_b(tile + 1);
+        compute_step<DT, T>(acc, stages + cur * STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * STAGE_BYTES, step_off(0),
+                            wave);
+#ifdef HVS_KERNEL_HOOKS
+        const bool prof = p.dbg & 512;
         unsigned long long c1 = 0, c2 = 0, c3 = 0;
         if (prof) c1 = clock64();
-        if (tile_end) {
-            if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
-            zero_acc(acc);
-        }
+#endif
+        if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+        zero_acc(acc);
+#ifdef HVS_KERNEL_HOOKS
         if (prof) c2 = clock64();
-        if (!(HVS_HOOK(p) & 4)) __syncthreads();  // the DMA of the next stage has landed (vmcnt) for every wave
+#endif
+        if (!(HVS_HOOK(p) & 4)) __syncthreads();
+        cur ^= 1;
+#ifdef HVS_KERNEL_HOOKS
         if (prof) c3 = clock64();
-        if (tile_end) {
-            compact_lists<FOLD, T>(p, b, wave, lane);
-            if (prof) {
-                const unsigned long long c4 = clock64();
-                pr_loop += c1 - pr_last;
-                pr_epi += c2 - c1;
-                pr_bar += c3 - c2;
-                pr_cmp += c4 - c3;
-                pr_last = c4;
-            }
-            // the next epilogue is a whole K loop (>= 1 barrier) away, so no extra barrier is needed
-            // unless the K loop has a single step
-            if (p.nks == 1) __syncthreads();
+#endif
+        compact_lists<FOLD, T>(p, b, wave, lane);
+#ifdef HVS_KERNEL_HOOKS
+        if (prof) {
+            const unsigned long long c4 = clock64();
+            pr_loop += c1 - pr_last;
+            pr_epi += c2 - c1;
+            pr_bar += c3 - c2;
+            pr_cmp += c4 - c3;
+            pr_last = c4;
         }
-        ks = nks_next;
-        tile = ntile;
+#endif
+        // the next epilogue is a whole K loop (>= 1 barrier) away, so no extra barrier is needed
+        // unless the K loop has a single step
+        if (p.nks == 1) __syncthreads();
     }
-    if ((HVS_HOOK(p) & 512) && lane == 0) {
+#ifdef HVS_KERNEL_HOOKS
+    if ((p.dbg & 512) && lane == 0) {
         atomicAdd(&p.prof[0], pr_loop);
         atomicAdd(&p.prof[1], pr_epi);
         atomicAdd(&p.prof[2], pr_bar);
         atomicAdd(&p.prof[3], pr_cmp);
     }
+#endif
     __syncthreads();
     publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
 #endif
