@@ -101,42 +101,44 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
     }
     __syncthreads();
 
-    int64_t tile = tile_lo;
-    int ks = 0;
     float x_is[NT];  // split operands: 1 / scale of this lane's rows
-    for (int64_t g = 0; g < total_steps; g++) {
-        const int cur = (int)(g & 1);
-        int ks_next = ks + 1;
-        int64_t ntile = tile;
-        if (ks_next == p.nks) { ks_next = 0; ntile = tile + 1; }
-        if (ks_next == 0 && g + 1 < total_steps) init_b(ntile);  // after the last step: re-fetch this tile's step 0 (unused)
-        if (ks == 0 && tid == 0 && (p.S & 7) == 0 && p.lockstep != nullptr && p.CT > 1)
+    // (centroid, row) byte offsets of k-step k inside a row.  All three products of split operands run three slab pairs,
+    // (hi, hi), (hi, lo), (lo, hi), of split_steps steps each; anything else is the first pair of a split that never ends
+    const int slab_steps = p.split_steps && !p.hi_only ? p.split_steps : 0x3fffffff;
+    auto step_off = [&](int k) {
+        const int slab = (k >= 2 * slab_steps ? 1 : 0) + (k >= slab_steps ? 1 : 0), w = k - slab * slab_steps;
+        return KOff{((slab == 2 ? slab_steps : 0) + w) * KB, ((slab == 1 ? slab_steps : 0) + w) * KB};
+    };
+    // A tile loop around a k loop without tile bookkeeping in it; the tile's last step (whose LDS-DMA fetches step 0 of the
+    // next tile) is written out after it.
+    int cur = 0;
+    for (int64_t tile = tile_lo; tile < tile_hi; tile++) {
+        if (tid == 0 && (p.S & 7) == 0 && p.lockstep != nullptr && p.CT > 1)
             lockstep_arrive(p.lockstep + s, (unsigned int)(tile - tile_lo + 1), p.CT, in_step);
-        if (ks == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                x_is[nt] = 1.0f;
-                if (p.x_split_inv) {
-                    const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
-                    if (row < p.n) {
-                        const float inv = p.x_inv[row];
-                        x_is[nt] = inv < __builtin_inff() ? p.x_split_inv[row] / inv : 1.0f;  // exact: the ratio is a power of two
-                    }
+        for (int nt = 0; nt < NT; nt++) {
+            x_is[nt] = 1.0f;
+            if (p.x_split_inv) {
+                const int64_t row = tile * T::BN + wn * (NT * 32) + nt * 32 + (lane & 31);
+                if (row < p.n) {
+                    const float inv = p.x_inv[row];
+                    x_is[nt] = inv < __builtin_inff() ? p.x_split_inv[row] / inv : 1.0f;  // exact: the ratio is a power of two
                 }
             }
         }
-        KOff next_off = koff_plain(ks_next);
-        if (p.split_steps && !p.hi_only) {
-            const int slab = ks_next >= 2 * p.split_steps ? 2 : (ks_next >= p.split_steps ? 1 : 0), w = ks_next - slab * p.split_steps;
-            next_off.a = ((slab == 2 ? p.split_steps : 0) + w) * KB;
-            next_off.b = ((slab == 1 ? p.split_steps : 0) + w) * KB;
+        for (int ks = 0; ks + 1 < p.nks; ks++) {
+            compute_step<DT, T>(acc, stages + cur * T::STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * T::STAGE_BYTES,
+                                step_off(ks + 1), wave);
+            __syncthreads();
+            cur ^= 1;
         }
+        if (tile + 1 < tile_hi) init_b(tile + 1);  // after the last tile: its own step 0 is fetched again (unused)
         compute_step<DT, T>(acc, stages + cur * T::STAGE_BYTES, wm, wn, lane, srcA, srcB, stages + (cur ^ 1) * T::STAGE_BYTES,
-                            next_off, wave);
+                            step_off(0), wave);
+        cur ^= 1;
 
         uint64_t bestk[NT];
-        const bool last = ks == p.nks - 1;
-        if (last && TOP2) {
+        if (TOP2) {
             static_assert(!TOP2 || T::BM <= 256, "the index within a tile is packed into 8 bits");
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) xch[(wn * NT + nt) * 32 + (lane & 31)] = bestk[nt];
             }
-        } else if (last) {
+        } else {
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 // per lane: strict "<" over increasing centroid index keeps the lowest index on ties
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
 
         __syncthreads();
 
-        if (last && wm == 0 && h == 0) {
+        if (wm == 0 && h == 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
                 const uint64_t o = xch[(wn * NT + nt) * 32 + (lane & 31)];
@@ -228,9 +230,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 256 ? 2 : 1) void kmeans_assign_ker
                 if (row < p.n) p.best[(size_t)ct * p.n + row] = b;
             }
         }
-        if (last && p.nks == 1) __syncthreads();  // xch is rewritten a whole K loop later otherwise
-        ks = ks_next;
-        tile = ntile;
+        if (p.nks == 1) __syncthreads();  // xch is rewritten a whole K loop later otherwise
     }
 #endif
 }
