@@ -269,7 +269,7 @@ __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const Block
     // of the 16 bounds -- one v_max3 chain, one multiply, one compare per tile; it is used once the block has
     // seen enough rows for most tiles to hold no survivor (about k / rows_seen of the scores survive).
     // Level 2, per group of four scores (four adjacent queries): the test proper.
-    const bool level1 = p.tau0 != nullptr || (int64_t)p.k * 4096 < (tile - tile_first) * T::BN;
+    const bool level1 = p.tau0 != nullptr || (int64_t)p.k * 512 < (tile - tile_first) * T::BN;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         f32x4 bnd[4];
