@@ -252,9 +252,21 @@ __device__ __forceinline__ void load_row_meta(const SearchParams &p, int64_t til
     }
 }
 
+// counter[0]++ in LDS, the old value returned (16-bit kernels; the fp32 kernel, whose k-steps are four times as long, measured
+// 1.3 % slower with it and keeps atomicAdd).  Written as the instruction itself: for an atomicAdd the compiler first
+// waits for every outstanding LDS-DMA fetch (vmcnt(0): it cannot tell the stage a fetch fills from the counters, both
+// lie in the block's one dynamic LDS array), i.e. the first survivor of a tile stalled its wave for the whole round trip
+// of the next tile's first k-step, which the rest of the epilogue is there to cover.
+__device__ __forceinline__ int lds_count_up(int *counter) {
+    const uint32_t at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)counter;
+    int old;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(at), "v"(1) : "memory");
+    return old;
+}
+
 // Epilogue of one block tile: prefilter every score against its query's bound, exact test for the
 // survivors, append to the query's candidate array.
-template <int FOLD, class T>
+template <int FOLD, class T, bool BARE_COUNT = false>
 __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const BlockState &b, f32x16 (&acc)[T::MT][T::NT],
                                               const float (&invn2)[T::NT], int64_t tile, int64_t tile_first, int wm, int wn,
                                               int lane) {
@@ -311,11 +323,12 @@ __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const Block
                     for (int e = 0; e < 4; e += FOLD) {
                         const int qv = (av + e) / FOLD;  // folded query, local to the tile
                         if (any && d[e] < b.tau[qv]) {
-                            const int pos = atomicAdd(&b.cnt[qv], 1);
+                            const int pos = BARE_COUNT ? lds_count_up(&b.cnt[qv]) : atomicAdd(&b.cnt[qv], 1);
                             if (pos < p.cap) {
-                                const int64_t row = n_base + nt * 32;
-                                const uint32_t rp = p.remap ? p.remap[row] : (uint32_t)row;
-                                b.my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), rp);
+                                // the row as this launch numbers it; a dense copy's numbers are mapped back when the lists
+                                // are published (the map is monotone, so ties keep their order) -- a load here would make
+                                // the store wait for every LDS-DMA fetch in flight as well
+                                b.my_cand[(size_t)qv * p.cap + pos] = hvs_make_key(hvs_ord(d[e]), (uint32_t)(n_base + nt * 32));
                             }
                             else *p.overflow = 1;
                         }
@@ -385,7 +398,9 @@ __device__ __forceinline__ void publish_lists_kl(const SearchParams &p, const Bl
 #pragma unroll
         for (int e = 0; e < KL; e++) {
             const int i = e * 64 + lane;
-            if (i < p.k) dst[i] = a[e];  // ascending, HVS_KEY_EMPTY padding sorts last
+            uint64_t key = a[e];
+            if (p.remap && key != HVS_KEY_EMPTY) key = (key & 0xFFFFFFFF00000000ull) | p.remap[(uint32_t)key];  // rows of a dense copy -> table positions
+            if (i < p.k) dst[i] = key;  // ascending, HVS_KEY_EMPTY padding sorts last
         }
     }
 }
@@ -487,7 +502,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         unsigned long long c1 = 0, c2 = 0, c3 = 0;
         if (prof) c1 = clock64();
 #endif
-        if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+        if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T, DT != HVS_F32>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
         zero_acc(acc);
 #ifdef HVS_KERNEL_HOOKS
         if (prof) c2 = clock64();
@@ -744,7 +759,7 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
                 }
                 col_tile = tile;
             } else {
-                tile_epilogue<FOLD, T>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
+                tile_epilogue<FOLD, T, true>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
             }
             zero_acc(acc);
         }
