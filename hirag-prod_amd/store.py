@@ -22,6 +22,7 @@ from __future__ import annotations
 import asyncio
 import logging
 import math
+import os
 import time
 from collections.abc import Mapping
 from datetime import datetime
@@ -44,6 +45,35 @@ _HALF_MAX = 65504.0
 _MAX_FOLD = 8  # HVS_MAX_FOLD
 _MAX_DIST_FOLD = 128  # HVS_MAX_DIST_FOLD: embeddings per call of the distance column / range search
 _MAX_FILTER_URIS = 8192  # HVS_MAX_FILTER_URIS: uri codes a device-evaluated filter takes
+
+_TRUE_WORDS = ("1", "true", "t", "yes", "y", "on")
+_FALSE_WORDS = ("0", "false", "f", "no", "n", "off")
+
+
+def env_use_half_vec(environ=None) -> bool:
+    """``USE_HALF_VEC`` as the reference's settings model reads it (``configs/envs.py:12-13``: a pydantic bool that
+    defaults to True), looked up when called, not at import time."""
+    raw = (os.environ if environ is None else environ).get("USE_HALF_VEC")
+    if raw is None or raw.strip() == "":
+        return True
+    word = raw.strip().lower()
+    if word in _TRUE_WORDS:
+        return True
+    if word in _FALSE_WORDS:
+        return False
+    raise ValueError(f"USE_HALF_VEC={raw!r}: expected one of {_TRUE_WORDS + _FALSE_WORDS}")
+
+
+def env_embedding_dimension(environ=None) -> Optional[int]:
+    """``EMBEDDING_DIMENSION`` (``configs/envs.py:12``; the reference's column type takes its width from it,
+    ``schema/vector_config.py:8-11``), or None when the variable is absent."""
+    raw = (os.environ if environ is None else environ).get("EMBEDDING_DIMENSION")
+    if raw is None or raw.strip() == "":
+        return None
+    dim = int(raw)
+    if dim <= 0:
+        raise ValueError(f"EMBEDDING_DIMENSION={raw!r}: expected a positive integer")
+    return dim
 
 
 class StoredVector(list):
@@ -271,7 +301,7 @@ class HipVectorStore(BaseVDB):
     def __init__(
         self,
         embedding_func: Optional[Callable],
-        vector_type: Literal["vector", "halfvec", "bf16"] = "halfvec",
+        vector_type: Optional[Literal["vector", "halfvec", "bf16"]] = None,
         embedding_dimension: Optional[int] = None,
         device: int = 0,
         delegate: Any = None,
@@ -285,7 +315,14 @@ class HipVectorStore(BaseVDB):
         """``search_copy``: a ``vector`` (fp32) table serves batched searches, single queries on large tables and
         k-means from a second, fp16-slab copy of its rows on the 16-bit matrix pipe -- several times faster, and as
         much device memory again as the rows.  False keeps every table at its own size (fp32 kernels only).  The
-        store logs one line per table when such a copy appears."""
+        store logs one line per table when such a copy appears.
+
+        ``vector_type`` None: the environment decides, as it does for the reference's column type
+        (``USE_HALF_VEC``, true unless set otherwise -> ``halfvec``; ``schema/vector_config.py:8-11``).
+        ``embedding_dimension`` None: ``EMBEDDING_DIMENSION`` when the variable is set (read when the first index is
+        made), else the width of the first vector stored."""
+        if vector_type is None:
+            vector_type = "halfvec" if env_use_half_vec() else "vector"
         if vector_type not in ("vector", "halfvec", "bf16"):
             raise ValueError(f"vector_type must be 'vector', 'halfvec' or 'bf16', got {vector_type!r}")
         self.embedding_func = embedding_func
@@ -311,7 +348,7 @@ class HipVectorStore(BaseVDB):
 
     # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
     @classmethod
-    def create(cls, embedding_func: Optional[Callable], vector_type: str = "halfvec", **kwargs) -> "HipVectorStore":
+    def create(cls, embedding_func: Optional[Callable], vector_type: Optional[str] = None, **kwargs) -> "HipVectorStore":
         return cls(embedding_func, vector_type=vector_type, **kwargs)
 
     # -- helpers -----------------------------------------------------------------------------------
@@ -333,7 +370,7 @@ class HipVectorStore(BaseVDB):
     def _ensure_index(self, table: _Table, dim: int):
         if table.index is None:
             if self.embedding_dimension is None:
-                self.embedding_dimension = dim
+                self.embedding_dimension = env_embedding_dimension() or dim
             table.index = self._make_index(self.embedding_dimension)
             if not self.search_copy and hasattr(table.index, "search_copy"):
                 table.index.search_copy(False)
@@ -366,6 +403,8 @@ class HipVectorStore(BaseVDB):
         """Create the embedded tables' indexes (``PGVector._init_vdb``, pgvector.py:704-726)."""
         if embedding_dimension is not None:
             self.embedding_dimension = int(embedding_dimension)
+        if self.embedding_dimension is None:
+            self.embedding_dimension = env_embedding_dimension()
         if self.embedding_dimension is None:
             return
         for table in self.tables.values():
@@ -459,7 +498,7 @@ class HipVectorStore(BaseVDB):
                 if pk in table.pk_map or pk in seen_in_batch:
                     continue  # first write wins
                 vec = np.asarray(row["vector"], dtype=np.float64)
-                dim = self.embedding_dimension or vec.shape[0]
+                dim = self.embedding_dimension or env_embedding_dimension() or vec.shape[0]
                 if vec.ndim != 1 or vec.shape[0] != dim:
                     raise ValueError(f"expected {dim} dimensions, not {vec.shape[0] if vec.ndim == 1 else vec.shape}")
                 if not np.all(np.isfinite(vec)):

@@ -101,3 +101,42 @@ def test_row_store_behaves_like_the_list_of_dicts_it_replaces():
     assert len(kept) == 2 and [x["documentKey"] for x in kept] == ["b", "d"] and kept[1]["chunkIdx"] == 3
     rows[2] = {"documentKey": "c", "text": "again"}
     assert rows[2]["text"] == "again"
+
+
+def test_env_names_of_the_reference_set_type_and_dimension(monkeypatch):
+    """configs/envs.py:12-13 + schema/vector_config.py:8-11: USE_HALF_VEC picks the column type, EMBEDDING_DIMENSION its
+    width; both are read when the store / its first index is made, not at import time."""
+    import hirag_prod_amd.store as st
+
+    made = []
+
+    def factory(dim, dtype, device):
+        made.append((dim, dtype))
+        return OracleIndex(dim, dtype, device)
+
+    monkeypatch.delenv("USE_HALF_VEC", raising=False)
+    monkeypatch.delenv("EMBEDDING_DIMENSION", raising=False)
+    assert st.HipVectorStore.create(None).vector_type == "halfvec"  # the reference's default
+    for word, expect in (("false", "vector"), ("0", "vector"), ("True", "halfvec"), ("on", "halfvec")):
+        monkeypatch.setenv("USE_HALF_VEC", word)
+        assert st.HipVectorStore.create(None).vector_type == expect
+        assert st.HipVectorStore.create(None, vector_type="bf16").vector_type == "bf16"  # an explicit argument wins
+    monkeypatch.setenv("USE_HALF_VEC", "maybe")
+    with pytest.raises(ValueError):
+        st.HipVectorStore.create(None)
+
+    monkeypatch.setenv("USE_HALF_VEC", "false")
+    monkeypatch.setenv("EMBEDDING_DIMENSION", "24")
+    s = st.HipVectorStore.create(store_cases.make_embedding_func(), index_factory=factory)
+    store_cases.run(s._init_vdb())  # no argument: the environment's width
+    assert s.embedding_dimension == 24 and made and all(m == (24, "f32") for m in made)
+    s2 = st.HipVectorStore.create(store_cases.make_embedding_func(), index_factory=factory)
+    store_cases.run(s2._init_vdb(embedding_dimension=16))  # StorageManager.initialize passes it explicitly
+    assert s2.embedding_dimension == 16
+
+    # a store whose first index is made by the first insert: the environment's width is the column's, and a vector of
+    # another width is refused like PostgreSQL refuses it
+    monkeypatch.setenv("EMBEDDING_DIMENSION", "5")
+    s3 = st.HipVectorStore.create(store_cases.make_embedding_func(), index_factory=factory)
+    with pytest.raises(ValueError, match="expected 5 dimensions"):
+        store_cases.run(s3.upsert_texts(["a text"], [{"documentKey": "k", "workspaceId": "w", "knowledgeBaseId": "b"}], "Chunks"))
