@@ -92,6 +92,9 @@ SIGNATURES = {
     ),
     "hvs_index_deleted_count": (c_int, [c_void_p, POINTER(c_int64)]),
     "hvs_index_compact": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
+    "hvs_index_partition": (c_int, [c_void_p, c_int, POINTER(c_int64), c_void_p]),
+    "hvs_index_partition_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    "hvs_index_set_ids": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "hvs_index_prepare": (c_int, [c_void_p, POINTER(c_int)]),
     "hvs_index_search_copy": (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     "hvs_index_export": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -136,7 +139,7 @@ def load_library() -> ctypes.CDLL:
     if "torch" not in sys.modules:
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:  # noqa: BLE001 -- no torch, or a torch that does not load here: the library then brings its own runtime
             pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():

@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float *__restrict__ 
         const uint64_t key = sorted[t];  // k <= kc
         const bool have = key != HVS_KEY_EMPTY;
         out_dist[(size_t)qi * k + t] = have ? hvs_unord((uint32_t)(key >> 32)) : __builtin_inff();
-        out_ids[(size_t)qi * k + t] = have ? ids[(uint32_t)key] : -1;
+        out_ids[(size_t)qi * k + t] = have ? (ids ? ids[(uint32_t)key] : (int64_t)(uint32_t)key) : -1;  // ids == nullptr: row positions
     }
     if (t == 0) {
         int n_valid = 0;
@@ -1360,7 +1360,7 @@ static int rescore_pass(hvs_index *idx, const float *d_q, const float *d_qinv, i
     HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, kc, group_filter, d_mask, thr + eps, row_begin, row_end, c_dist, c_pos, c_cnt, 3));
     HVS_REQUIRE(idx->q_rel && idx->split_rel, "hvs_search: the filter pass left no error measure of its operands");
     HVS_TRY(hvs_prof_begin(idx));
-    rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
+    rescore_kernel<<<nq, 256, 0, idx->stream>>>((const float *)idx->rows, idx->ld, idx->inv_norm, idx->emit_positions ? nullptr : idx->ids, d_q, d_qinv, fold, c_dist, c_pos,
                                                 c_cnt, kc, k, thr, eps, idx->q_rel, padded_fold(fold), idx->split_rel, eps_tail, d_dist, d_ids,
                                                 d_count, d_redo);
     HVS_HIP(hipGetLastError());

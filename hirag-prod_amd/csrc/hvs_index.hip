@@ -427,7 +427,7 @@ int hvs_live_gather(hvs_index *idx, const void *src_rows, const float *src_inv, 
 __global__ void set_attrs_kernel(int4 *__restrict__ attrs, int64_t first, int64_t n, const int32_t *__restrict__ ws,
                                  const int32_t *__restrict__ kb, const int32_t *__restrict__ uri, const uint8_t *__restrict__ priv) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int4 a = attrs[first + i];
+        int4 a = attrs[first + i];  // a field no call has set yet reads -1 and matches no clause
         if (ws) a.x = ws[i];
         if (kb) a.y = kb[i];
         if (uri) a.z = uri[i];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(const int4 *__restrict
             const int4 a = attrs[row];
             if (ws >= 0) ok = a.x == ws;
             if (ok && kb >= 0) ok = a.y == kb;
-            if (ok && access >= 0) ok = (a.w != 0) == (access != 0);
+            if (ok && access >= 0) ok = a.w >= 0 && (a.w != 0) == (access != 0);
             if (ok && uris) {
                 int lo = 0, hi = n_uris;  // first entry >= a.z
                 while (lo < hi) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(const int4 *__restrict
 int hvs_attrs_ensure(hvs_index *idx) {
     if (idx->attrs || idx->cap == 0) return 0;
     HVS_HIP(hipMalloc((void **)&idx->attrs, (size_t)idx->cap * sizeof(int4)));
-    HVS_HIP(hipMemsetAsync(idx->attrs, 0, (size_t)idx->cap * sizeof(int4), idx->stream));
+    HVS_HIP(hipMemsetAsync(idx->attrs, 0xFF, (size_t)idx->cap * sizeof(int4), idx->stream));  // -1: no value yet, matches no clause
     return 0;
 }
 
@@ -607,12 +607,12 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
 }
 
 template <typename P>
-static int grow(hvs_index *idx, P **ptr, size_t old_count, size_t new_count, bool zero_new = false) {
+static int grow(hvs_index *idx, P **ptr, size_t old_count, size_t new_count, bool zero_new = false, int fill_byte = 0) {
     P *np = nullptr;
     HVS_HIP(hipMalloc((void **)&np, new_count * sizeof(P)));
     if (*ptr && old_count) HVS_HIP(hipMemcpyAsync(np, *ptr, old_count * sizeof(P), hipMemcpyDeviceToDevice, idx->stream));
     if (zero_new && new_count > old_count)
-        HVS_HIP(hipMemsetAsync(np + old_count, 0, (new_count - old_count) * sizeof(P), idx->stream));
+        HVS_HIP(hipMemsetAsync(np + old_count, fill_byte, (new_count - old_count) * sizeof(P), idx->stream));
     HVS_HIP(hipStreamSynchronize(idx->stream));
     if (*ptr) HVS_HIP(hipFree(*ptr));
     *ptr = np;
@@ -643,7 +643,7 @@ extern "C" int hvs_index_reserve(hvs_index *idx, int64_t capacity_rows) {
     HVS_TRY(grow(idx, &idx->groups, (size_t)idx->n, (size_t)capacity_rows));
     if (idx->deleted)
         HVS_TRY(grow(idx, &idx->deleted, (size_t)(idx->cap + 31) / 32, (size_t)(capacity_rows + 31) / 32, true));
-    if (idx->attrs) HVS_TRY(grow(idx, &idx->attrs, (size_t)idx->cap, (size_t)capacity_rows, true));
+    if (idx->attrs) HVS_TRY(grow(idx, &idx->attrs, (size_t)idx->cap, (size_t)capacity_rows, true, 0xFF));
     idx->cap = capacity_rows;
     return 0;
 }
@@ -892,86 +892,295 @@ extern "C" int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *
     return 0;
 }
 
+// The table's arrays replaced by the rows at `positions` (device memory, n_live entries, any order), in that order:
+// new arrays sized for them, the old ones released only when every copy has succeeded.  Tombstones are gone afterwards
+// (the caller lists live rows only).  renumber_ids: ids become the new positions.
+static int rebuild_rows(hvs_index *idx, const uint32_t *positions, int64_t n_live, int renumber_ids, const char *who) {
+    const size_t pitch = (size_t)idx->ld * idx->elem_size;
+    const int64_t cap = n_live > 1024 ? n_live : 1024;
+    char *rows = nullptr;
+    float *inv = nullptr;
+    int64_t *ids = nullptr;
+    int32_t *groups = nullptr;
+    int4 *attrs = nullptr;
+    int rc = 0;
+    do {
+        hipError_t e;
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)cap * (pitch + 16 + (idx->attrs ? sizeof(int4) : 0)) + HVS_ROWS_SLACK;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < need + ((size_t)64 << 20)) {
+            hvs_set_error("%s: the rows move into new arrays of %.2f GB, %.2f GB of device memory are free", who, need / 1e9, free_b / 1e9);
+            rc = 1;
+            break;
+        }
+        if (idx->attrs && (e = hipMalloc((void **)&attrs, (size_t)cap * sizeof(int4))) != hipSuccess) {
+            hvs_set_error("%s: hipMalloc failed: %s", who, hipGetErrorString(e));
+            rc = 1;
+            break;
+        }
+        if (attrs && (e = hipMemsetAsync(attrs, 0xFF, (size_t)cap * sizeof(int4), idx->stream)) != hipSuccess) {
+            hvs_set_error("%s: %s", who, hipGetErrorString(e));
+            rc = 1;
+            break;
+        }
+        if ((e = hipMalloc((void **)&rows, (size_t)cap * pitch + HVS_ROWS_SLACK)) != hipSuccess ||
+            (e = hipMalloc((void **)&inv, (size_t)cap * 4)) != hipSuccess || (e = hipMalloc((void **)&ids, (size_t)cap * 8)) != hipSuccess ||
+            (e = hipMalloc((void **)&groups, (size_t)cap * 4)) != hipSuccess) {
+            hvs_set_error("%s: hipMalloc failed: %s", who, hipGetErrorString(e));
+            rc = 1;
+            break;
+        }
+        if ((e = hipMemsetAsync(rows + (size_t)n_live * pitch, 0, (size_t)(cap - n_live) * pitch + HVS_ROWS_SLACK, idx->stream)) != hipSuccess) {
+            hvs_set_error("%s: %s", who, hipGetErrorString(e));
+            rc = 1;
+            break;
+        }
+        if (n_live > 0) {
+            if ((rc = hvs_live_gather(idx, idx->rows, idx->inv_norm, idx->ld * idx->elem_size, positions, n_live, rows, inv)) != 0) break;
+            gather_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->ids, idx->groups, positions, n_live, ids, groups);
+            if (attrs) gather_attrs_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->attrs, positions, n_live, attrs);
+            if (renumber_ids) fill_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(ids, groups, n_live, 0, 0, 0, nullptr, groups);
+        }
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(idx->stream)) != hipSuccess) {
+            hvs_set_error("%s: %s", who, hipGetErrorString(e));
+            rc = 1;
+        }
+    } while (0);
+    if (rc != 0) {
+        (void)hipFree(rows);
+        (void)hipFree(inv);
+        (void)hipFree(ids);
+        (void)hipFree(groups);
+        (void)hipFree(attrs);
+        return rc;
+    }
+    (void)hipFree(idx->rows);
+    (void)hipFree(idx->inv_norm);
+    (void)hipFree(idx->ids);
+    (void)hipFree(idx->groups);
+    (void)hipFree(idx->deleted);
+    idx->rows = rows;
+    idx->inv_norm = inv;
+    idx->ids = ids;
+    idx->groups = groups;
+    if (attrs) {
+        (void)hipFree(idx->attrs);
+        idx->attrs = attrs;
+    }
+    idx->deleted = nullptr;
+    idx->n_deleted = 0;
+    idx->n = n_live;
+    hvs_split_invalidate(idx, 0);
+    idx->split_failed = false;  // the table changed size or order: the copy may fit now
+    idx->cap = cap;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// group-partitioned order
+// ---------------------------------------------------------------------------
+// stats[0] = smallest group code of a live row, [1] = largest, [2] = rows whose code is below their predecessor's
+__global__ void part_stats_kernel(const int32_t *__restrict__ groups, const uint32_t *__restrict__ deleted, int64_t n, int *__restrict__ stats) {
+    int lo = INT32_MAX, hi = INT32_MIN, disorder = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = groups[i];
+        if (i > 0 && g < groups[i - 1]) disorder = 1;
+        if (deleted && ((deleted[i >> 5] >> (i & 31)) & 1u)) continue;
+        lo = g < lo ? g : lo;
+        hi = g > hi ? g : hi;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const int l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        disorder |= __shfl_xor(disorder, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&stats[0], lo);
+        atomicMax(&stats[1], hi);
+        if (disorder) atomicOr(&stats[2], 1);
+    }
+}
+
+// sort key of a row: its group code, or dead_key (above every code) for a deleted row
+__global__ void part_keys_kernel(const int32_t *__restrict__ groups, const uint32_t *__restrict__ deleted, int64_t n, uint32_t dead_key,
+                                 uint32_t *__restrict__ keys) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool dead = deleted && ((deleted[i >> 5] >> (i & 31)) & 1u);
+        keys[i] = dead ? dead_key : (uint32_t)groups[i];
+    }
+}
+
+// (code, first row) of every run of equal codes in groups[0, n); the runs arrive in any order, *count may pass capacity
+__global__ void part_runs_kernel(const int32_t *__restrict__ groups, int64_t n, unsigned int capacity, unsigned int *__restrict__ count,
+                                 int64_t *__restrict__ runs) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = groups[i];
+        if (i == 0 || g != groups[i - 1]) {
+            const unsigned int slot = atomicAdd(count, 1u);
+            if (slot < capacity) {
+                runs[2 * (size_t)slot] = g;
+                runs[2 * (size_t)slot + 1] = i;
+            }
+        }
+    }
+}
+
+__global__ void widen_positions_kernel(const uint32_t *__restrict__ src, int64_t n, int64_t *__restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+#define PART_MAX_GROUPS (1u << 22)  // runs of equal codes the range table holds (32 MB of staging); beyond it the table has no partition
+
+bool hvs_part_range(const hvs_index *idx, int32_t code, int64_t *begin, int64_t *end) {
+    if (idx->part_n <= 0) return false;
+    const auto it = std::lower_bound(idx->part_codes.begin(), idx->part_codes.end(), code);
+    if (it == idx->part_codes.end() || *it != code) {
+        *begin = *end = 0;  // no row of the ordered part carries this code
+        return true;
+    }
+    const size_t i = (size_t)(it - idx->part_codes.begin());
+    *begin = idx->part_begin[i];
+    *end = idx->part_begin[i + 1];
+    return true;
+}
+
+// Range table of rows [0, part_n), which must be ordered by group code.
+static int build_part_table(hvs_index *idx, int64_t part_n) {
+    idx->part_n = 0;
+    idx->part_codes.clear();
+    idx->part_begin.clear();
+    if (part_n <= 0) return 0;
+    void *ws = nullptr;
+    const unsigned int capacity = part_n < (int64_t)PART_MAX_GROUPS ? (unsigned int)part_n : PART_MAX_GROUPS;  // a run has at least one row
+    HVS_TRY(hvs_ws_get(idx, 5, 256 + (size_t)capacity * 16, &ws));
+    unsigned int *d_count = (unsigned int *)ws;
+    int64_t *d_runs = (int64_t *)((char *)ws + 256);
+    HVS_HIP(hipMemsetAsync(d_count, 0, 4, idx->stream));
+    part_runs_kernel<<<grid_for(part_n), 256, 0, idx->stream>>>(idx->groups, part_n, capacity, d_count, d_runs);
+    HVS_HIP(hipGetLastError());
+    unsigned int n_runs = 0;
+    HVS_HIP(hipMemcpyAsync(&n_runs, d_count, 4, hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    HVS_REQUIRE(n_runs <= capacity, "hvs_index_partition: %u runs of group codes, the range table holds %u", n_runs, capacity);
+    std::vector<int64_t> runs((size_t)n_runs * 2);
+    HVS_HIP(hipMemcpy(runs.data(), d_runs, runs.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<std::pair<int64_t, int32_t>> by_begin(n_runs);
+    for (unsigned int i = 0; i < n_runs; i++) by_begin[i] = {runs[2 * (size_t)i + 1], (int32_t)runs[2 * (size_t)i]};
+    std::sort(by_begin.begin(), by_begin.end());
+    idx->part_codes.reserve(n_runs);
+    idx->part_begin.reserve((size_t)n_runs + 1);
+    for (unsigned int i = 0; i < n_runs; i++) {
+        HVS_REQUIRE(i == 0 || by_begin[i].second > by_begin[i - 1].second, "hvs_index_partition: rows [0, %lld) are not ordered by group code",
+                    (long long)part_n);
+        idx->part_codes.push_back(by_begin[i].second);
+        idx->part_begin.push_back(by_begin[i].first);
+    }
+    idx->part_begin.push_back(part_n);
+    idx->part_n = part_n;
+    return 0;
+}
+
+extern "C" int hvs_index_partition(hvs_index *idx, int renumber_ids, int64_t *out_rows, int64_t *out_old_positions) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_partition: idx is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    const int64_t n = idx->n;
+    if (n == 0) {
+        idx->part_n = 0;
+        idx->part_codes.clear();
+        idx->part_begin.clear();
+        if (out_rows) *out_rows = 0;
+        return 0;
+    }
+    HVS_REQUIRE(n < (int64_t)0xFFFFFFFFll, "hvs_index_partition: row positions beyond 2^32 - 2");
+    const uint32_t *dead = idx->n_deleted > 0 ? idx->deleted : nullptr;
+    // staging (workspace 6): [stats][keys n][order n][sort scratch]
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_keys = 256, o_order = o_keys + up((size_t)n * 4), o_tmp = o_order + up((size_t)n * 4);
+    void *ws = nullptr;
+    HVS_TRY(hvs_ws_get(idx, 6, o_tmp + hvs_sort_temp_bytes(n), &ws));
+    int *d_stats = (int *)ws;
+    uint32_t *d_keys = (uint32_t *)((char *)ws + o_keys), *d_order = (uint32_t *)((char *)ws + o_order);
+    const int init[3] = {INT32_MAX, INT32_MIN, 0};
+    HVS_HIP(hipMemcpyAsync(d_stats, init, sizeof(init), hipMemcpyHostToDevice, idx->stream));
+    part_stats_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->groups, dead, n, d_stats);
+    HVS_HIP(hipGetLastError());
+    int stats[3] = {0, 0, 0};
+    HVS_HIP(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    const bool any_live = idx->n_deleted < n;
+    HVS_REQUIRE(!any_live || stats[0] >= 0, "hvs_index_partition: group code %d; the partition takes codes >= 0 (a filter can name no other)", stats[0]);
+    const bool in_order = stats[2] == 0 && idx->n_deleted == 0;
+    if (!in_order) {
+        const uint32_t dead_key = any_live ? (uint32_t)stats[1] + 1u : 0u;
+        int key_bits = 1;
+        while (key_bits < 32 && (dead_key >> key_bits) != 0) key_bits++;
+        part_keys_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->groups, dead, n, dead_key, d_keys);
+        HVS_HIP(hipGetLastError());
+        HVS_TRY(hvs_sort_by_key(idx->stream, d_keys, n, key_bits, d_order, (char *)ws + o_tmp));
+        const int64_t n_live = n - idx->n_deleted;
+        if (out_old_positions && n_live > 0) {  // before the rows move: the order lives in a workspace the range table reuses
+            widen_positions_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(d_order, n_live, (int64_t *)((char *)ws + o_tmp));
+            HVS_HIP(hipGetLastError());
+            HVS_HIP(hipMemcpyAsync(out_old_positions, (char *)ws + o_tmp, (size_t)n_live * 8, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+        }
+        HVS_TRY(rebuild_rows(idx, d_order, n_live, renumber_ids, "hvs_index_partition"));
+    } else {
+        if (out_old_positions)
+            for (int64_t i = 0; i < n; i++) out_old_positions[i] = i;
+        if (renumber_ids) {
+            fill_meta_kernel<<<grid_for(n), 256, 0, idx->stream>>>(idx->ids, idx->groups, n, 0, 0, 0, nullptr, idx->groups);
+            HVS_HIP(hipGetLastError());
+        }
+    }
+    HVS_TRY(build_part_table(idx, idx->n));
+    if (out_rows) *out_rows = idx->n;
+    return 0;
+}
+
+extern "C" int hvs_index_partition_info(hvs_index *idx, int64_t *ordered_rows, int64_t *n_groups) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_partition_info: idx is NULL");
+    if (ordered_rows) *ordered_rows = idx->part_n;
+    if (n_groups) *n_groups = (int64_t)idx->part_codes.size();
+    return 0;
+}
+
+extern "C" int hvs_index_set_ids(hvs_index *idx, int64_t first_pos, int64_t n, const int64_t *ids) {
+    HVS_REQUIRE(idx != nullptr, "hvs_index_set_ids: idx is NULL");
+    HVS_REQUIRE(first_pos >= 0 && n >= 0 && first_pos + n <= idx->n, "hvs_index_set_ids: rows [%lld, %lld) outside [0, %lld)",
+                (long long)first_pos, (long long)(first_pos + n), (long long)idx->n);
+    if (n == 0) return 0;
+    HVS_REQUIRE(ids != nullptr, "hvs_index_set_ids: ids is NULL");
+    HVS_HIP(hipSetDevice(idx->device));
+    HVS_HIP(hipMemcpyAsync(idx->ids + first_pos, ids, (size_t)n * 8, hipMemcpyHostToDevice, idx->stream));
+    HVS_HIP(hipStreamSynchronize(idx->stream));
+    return 0;
+}
+
 extern "C" int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows) {
     HVS_REQUIRE(idx != nullptr, "hvs_index_compact: idx is NULL");
     HVS_HIP(hipSetDevice(idx->device));
     if (idx->n_deleted > 0 && idx->n > 0) {
+        // compaction keeps the order of the survivors, so the ordered part of a partitioned table stays ordered: it
+        // shrinks to its live rows and the range table is rebuilt below
+        uint32_t part_live = 0;
+        if (idx->part_n > 0) {
+            hvs_live_params lpp{idx->groups, nullptr, idx->deleted, -1, 0, idx->part_n};
+            HVS_TRY(hvs_live_count(idx, lpp, &part_live));
+        }
         hvs_live_params lp{idx->groups, nullptr, idx->deleted, -1, 0, idx->n};
         uint32_t n_live = 0;
         HVS_TRY(hvs_live_count(idx, lp, &n_live));
-        const size_t pitch = (size_t)idx->ld * idx->elem_size;
-        const int64_t cap = n_live > 1024 ? (int64_t)n_live : 1024;
         uint32_t *positions = nullptr;
-        char *rows = nullptr;
-        float *inv = nullptr;
-        int64_t *ids = nullptr;
-        int32_t *groups = nullptr;
-        int4 *attrs = nullptr;
+        hipError_t e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4);
+        HVS_REQUIRE(e == hipSuccess, "hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
         int rc = 0;
-        do {  // new arrays sized for the survivors; the old ones are released only when every copy has succeeded
-            hipError_t e;
-            if (idx->attrs && (e = hipMalloc((void **)&attrs, (size_t)cap * sizeof(int4))) != hipSuccess) {
-                hvs_set_error("hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
-                rc = 1;
-                break;
-            }
-            if (attrs && (e = hipMemsetAsync(attrs, 0, (size_t)cap * sizeof(int4), idx->stream)) != hipSuccess) {
-                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
-                rc = 1;
-                break;
-            }
-            if ((e = hipMalloc((void **)&positions, (size_t)n_live * 4 + 4)) != hipSuccess || (e = hipMalloc((void **)&rows, (size_t)cap * pitch + HVS_ROWS_SLACK)) != hipSuccess ||
-                (e = hipMalloc((void **)&inv, (size_t)cap * 4)) != hipSuccess || (e = hipMalloc((void **)&ids, (size_t)cap * 8)) != hipSuccess ||
-                (e = hipMalloc((void **)&groups, (size_t)cap * 4)) != hipSuccess) {
-                hvs_set_error("hvs_index_compact: hipMalloc failed: %s", hipGetErrorString(e));
-                rc = 1;
-                break;
-            }
-            if ((e = hipMemsetAsync(rows + (size_t)n_live * pitch, 0, (size_t)(cap - n_live) * pitch + HVS_ROWS_SLACK, idx->stream)) != hipSuccess) {
-                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
-                rc = 1;
-                break;
-            }
-            if (n_live > 0) {
-                if ((rc = hvs_live_write(idx, lp, positions)) != 0) break;
-                if ((rc = hvs_live_gather(idx, idx->rows, idx->inv_norm, idx->ld * idx->elem_size, positions, n_live, rows, inv)) != 0) break;
-                gather_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->ids, idx->groups, positions, n_live, ids, groups);
-                if (attrs) gather_attrs_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(idx->attrs, positions, n_live, attrs);
-                if (renumber_ids) fill_meta_kernel<<<grid_for(n_live), 256, 0, idx->stream>>>(ids, groups, n_live, 0, 0, 0, nullptr, groups);
-            }
-            if ((e = hipGetLastError()) != hipSuccess || (e = hipStreamSynchronize(idx->stream)) != hipSuccess) {
-                hvs_set_error("hvs_index_compact: %s", hipGetErrorString(e));
-                rc = 1;
-            }
-        } while (0);
+        if (n_live > 0) rc = hvs_live_write(idx, lp, positions);
+        if (rc == 0) rc = rebuild_rows(idx, positions, n_live, renumber_ids, "hvs_index_compact");
         (void)hipFree(positions);
-        if (rc != 0) {
-            (void)hipFree(rows);
-            (void)hipFree(inv);
-            (void)hipFree(ids);
-            (void)hipFree(groups);
-            (void)hipFree(attrs);
-            return rc;
-        }
-        (void)hipFree(idx->rows);
-        (void)hipFree(idx->inv_norm);
-        (void)hipFree(idx->ids);
-        (void)hipFree(idx->groups);
-        (void)hipFree(idx->deleted);
-        idx->rows = rows;
-        idx->inv_norm = inv;
-        idx->ids = ids;
-        idx->groups = groups;
-        if (attrs) {
-            (void)hipFree(idx->attrs);
-            idx->attrs = attrs;
-        }
-        idx->deleted = nullptr;
-        idx->n_deleted = 0;
-        idx->n = n_live;
-        hvs_split_invalidate(idx, 0);
-        idx->split_failed = false;  // the table shrank: the copy may fit now
-        idx->cap = cap;
+        if (rc != 0) return rc;
+        if (idx->part_n > 0) HVS_TRY(build_part_table(idx, part_live));
     } else if (renumber_ids && idx->n > 0) {
         fill_meta_kernel<<<grid_for(idx->n), 256, 0, idx->stream>>>(idx->ids, idx->groups, idx->n, 0, 0, 0, nullptr, idx->groups);
         HVS_HIP(hipGetLastError());

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/hvs.h"
 
@@ -67,6 +68,14 @@ struct hvs_index {
     int64_t n = 0;
     int64_t cap = 0;
 
+    // group-partitioned order (hvs_index_partition): rows [0, part_n) are ordered by group code, part_codes (ascending)
+    // and part_begin (one more entry than codes; the last is part_n) give every code its row range, so that a search
+    // with a group filter scans a range without testing a code; rows [part_n, n) arrived afterwards, in any order
+    int64_t part_n = 0;
+    std::vector<int32_t> part_codes;
+    std::vector<int64_t> part_begin;
+    bool emit_positions = false;  // set around the two sub-searches of a (range, tail) pair: their ids are row positions
+
     // fp32 indexes only: the rows as pairs of fp16 slabs for the 16-bit MFMA pipe (hvs_split.hip), built on the first
     // batched search and extended after appends; rows [0, split_n) are current
     void *split = nullptr;
@@ -84,9 +93,10 @@ struct hvs_index {
     bool filter_long = false;  // the short candidate lists (4 k) failed for most of a batch: start with the long ones (MFMA_MAX_K)
     int km_filter_skip = 0, km_filter_backoff = 0;  // the same for the k-means assignment's filter pass (more than a quarter of the rows flagged)
 
-    hvs_workspace ws[10];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
+    hvs_workspace ws[11];  // scratch buffers reused across calls (contents are lost when one grows): 0 queries, 1/2 candidate
                            // lists, 3 staging, 4 MFMA A operand, 5 live-row counts, 6 compacted rows of a filtered search,
-                           // 7 candidates of the filter pass (hvs_search_rescore), 8 row bitmask of an hvs_filter, 9 its uri codes
+                           // 7 candidates of the filter pass (hvs_search_rescore), 8 row bitmask of an hvs_filter, 9 its uri codes,
+                           // 10 the two lists of a (group range, tail) search
 
     void *h_pin = nullptr;  // pinned host buffer: the results of a search cross to the host in one copy
     size_t h_pin_bytes = 0;
@@ -138,6 +148,10 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
 int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_t group_filter, const uint32_t *row_mask,
                           bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, int64_t capacity,
                           float *out_dist, int64_t *out_ids, int64_t *out_total, int on_device);
+// the row range of a group code in the partitioned part of the table; false when the table has no partition
+bool hvs_part_range(const hvs_index *idx, int32_t code, int64_t *begin, int64_t *end);
+size_t hvs_sort_temp_bytes(int64_t n);  // hvs_sort.hip
+int hvs_sort_by_key(hipStream_t st, const uint32_t *keys, int64_t n, int key_bits, uint32_t *order_out, void *tmp);
 int hvs_noalloc_setup(int device);  // hvs_scan.hip: address of the scratch array of hvs_search_noalloc on `device` (current)
 
 int hvs_split_rows(hipStream_t st, const float *src, const float *src_inv, int64_t first, int64_t n, int cols, int ld_src, int ld16,

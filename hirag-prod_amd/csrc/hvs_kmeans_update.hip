@@ -1,5 +1,5 @@
 // M-step partial sums of the k-means step without floating-point atomics: rows are grouped by their
-// assignment with a stable radix sort of (assignment, row number) pairs, then every centroid's rows are
+// assignment with the library's stable counting sort (hvs_sort.hip), then every centroid's rows are
 // added up in ascending row order by blocks that own a slice of them.  The sums are bit-reproducible
 // (fixed order of additions) and the pass is bandwidth-shaped: the rows are read once, whole rows at a
 // time, where the atomic version was bound by the chip's atomic rate (~0.8 TB/s of added bytes).
@@ -7,8 +7,6 @@
 // The k-means step has no counterpart in the reference (its only clustering is scikit-learn's ward
 // linkage over <= 10 vectors, cluster/hierachical_cluster.py:51-103); it is defined by the float64 oracle.
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "hvs_internal.h"
 
@@ -20,7 +18,7 @@
 // per row, all aimed at a few thousand addresses, took 8.5 ms for 10M rows; this takes a fraction of a millisecond.
 #define UPD_LDS_BUCKETS 16384
 __global__ __launch_bounds__(1024) void upd_keys_kernel(const int32_t *__restrict__ assign, int64_t n, uint32_t *__restrict__ keys,
-                                                        uint32_t *__restrict__ vals, uint32_t *__restrict__ hist, int buckets) {
+                                                        uint32_t *__restrict__ hist, int buckets) {
     __shared__ uint32_t local[UPD_LDS_BUCKETS];
     const bool in_lds = buckets <= UPD_LDS_BUCKETS;
     if (in_lds) {
@@ -30,7 +28,6 @@ __global__ __launch_bounds__(1024) void upd_keys_kernel(const int32_t *__restric
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t key = (uint32_t)(assign[i] + 1);  // 0 = row without an assignment (deleted)
         keys[i] = key;
-        vals[i] = (uint32_t)i;
         if (in_lds) atomicAdd(&local[key], 1u);  // integer: order-independent
         else atomicAdd(&hist[key], 1u);
     }
@@ -186,37 +183,32 @@ int hvs_kmeans_update(hvs_index *idx, const int32_t *d_assign, int64_t n, int K,
     while ((1 << bits) < buckets) bits++;
     const int64_t max_slices = n / UPD_SLICE_ROWS + K;  // every centroid has at most one short slice
 
-    size_t temp_bytes = 0;
-    HVS_HIP(rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                      (uint32_t *)nullptr, (size_t)n, 0, bits, st));
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t o_keys_in = 0, o_keys_out = o_keys_in + up((size_t)n * 4), o_vals_in = o_keys_out + up((size_t)n * 4),
-                 o_vals_out = o_vals_in + up((size_t)n * 4), o_hist = o_vals_out + up((size_t)n * 4),
+    const size_t o_keys = 0, o_order = o_keys + up((size_t)n * 4), o_hist = o_order + up((size_t)n * 4),
                  o_start = o_hist + up((size_t)buckets * 4), o_slices = o_start + up((size_t)(buckets + 1) * 4),
-                 o_temp = o_slices + up((size_t)(K + 1) * 4), o_partial = o_temp + up(temp_bytes),
+                 o_temp = o_slices + up((size_t)(K + 1) * 4), o_partial = o_temp + up(hvs_sort_temp_bytes(n)),
                  total = o_partial + (size_t)max_slices * ld * 4;
     void *ws = nullptr;
     HVS_TRY(hvs_ws_get(idx, 6, total, &ws));
     char *w = (char *)ws;
-    uint32_t *keys_in = (uint32_t *)(w + o_keys_in), *keys_out = (uint32_t *)(w + o_keys_out);
-    uint32_t *vals_in = (uint32_t *)(w + o_vals_in), *vals_out = (uint32_t *)(w + o_vals_out);
+    uint32_t *keys = (uint32_t *)(w + o_keys), *order = (uint32_t *)(w + o_order);
     uint32_t *hist = (uint32_t *)(w + o_hist), *start = (uint32_t *)(w + o_start), *slice_start = (uint32_t *)(w + o_slices);
     float *partial = (float *)(w + o_partial);
 
     HVS_HIP(hipMemsetAsync(hist, 0, (size_t)buckets * 4, st));
     int g = (int)((n + 1023) / 1024);
     if (g > 512) g = 512;  // two blocks per CU: each adds its counters to the global ones once
-    upd_keys_kernel<<<g, 1024, 0, st>>>(d_assign, n, keys_in, vals_in, hist, buckets);
+    upd_keys_kernel<<<g, 1024, 0, st>>>(d_assign, n, keys, hist, buckets);
     upd_scan_kernel<<<1, 1024, 0, st>>>(hist, buckets, start, slice_start, (long long *)d_counts);
     HVS_HIP(hipGetLastError());
-    HVS_HIP(rocprim::radix_sort_pairs(w + o_temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, bits, st));
+    HVS_TRY(hvs_sort_by_key(st, keys, n, bits, order, w + o_temp));  // rows grouped by key, ascending row number inside a key
     const int cols4 = (ld / 4 + UPD_THREADS - 1) / UPD_THREADS;
     const float *X = (const float *)idx->rows;
-    if (cols4 <= 1) launch_sum<1>((int)max_slices, st, X, ld, vals_out, start, slice_start, K, partial);
-    else if (cols4 <= 2) launch_sum<2>((int)max_slices, st, X, ld, vals_out, start, slice_start, K, partial);
-    else if (cols4 <= 4) launch_sum<4>((int)max_slices, st, X, ld, vals_out, start, slice_start, K, partial);
-    else if (cols4 <= 8) launch_sum<8>((int)max_slices, st, X, ld, vals_out, start, slice_start, K, partial);
-    else launch_sum<16>((int)max_slices, st, X, ld, vals_out, start, slice_start, K, partial);
+    if (cols4 <= 1) launch_sum<1>((int)max_slices, st, X, ld, order, start, slice_start, K, partial);
+    else if (cols4 <= 2) launch_sum<2>((int)max_slices, st, X, ld, order, start, slice_start, K, partial);
+    else if (cols4 <= 4) launch_sum<4>((int)max_slices, st, X, ld, order, start, slice_start, K, partial);
+    else if (cols4 <= 8) launch_sum<8>((int)max_slices, st, X, ld, order, start, slice_start, K, partial);
+    else launch_sum<16>((int)max_slices, st, X, ld, order, start, slice_start, K, partial);
     HVS_HIP(hipGetLastError());
     int gf = (int)(((int64_t)K * dim + 255) / 256);
     if (gf > 256 * 16) gf = 256 * 16;

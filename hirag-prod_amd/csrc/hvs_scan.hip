@@ -606,7 +606,8 @@ static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int n
         uint64_t *t = in; in = out; out = t;
         P = P2;
     }
-    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, positions ? nullptr : idx->ids, d_dist, d_ids, d_count);
+    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, (positions || idx->emit_positions) ? nullptr : idx->ids, d_dist,
+                                                                      d_ids, d_count);
     HVS_HIP(hipGetLastError());
     return 0;
 }
@@ -851,6 +852,98 @@ extern "C" int hvs_search_filtered(hvs_index *idx, const float *queries, int nq,
                            out_ids, out_count, on_device, algo);
 }
 
+// One search over rows [row_begin, row_end) with prepared queries and device outputs: picks the route (scan, matrix
+// pipe, filter pass + exact rescoring) as the header describes.
+static int search_range(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                        const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids, int32_t *d_count,
+                        int algo) {
+    const int nq_total = nq * fold;
+    bool use_mfma = false;
+    if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32 || algo == HVS_ALGO_MFMA_SPLIT) {
+        HVS_REQUIRE(hvs_mfma_supported(idx, nq, fold, k), "hvs_search: the MFMA path does not support this shape (dtype %d, dim %d, fold %d, k %d)", idx->dtype, idx->dim, fold, k);
+        use_mfma = true;
+    } else if (algo == HVS_ALGO_AUTO) {
+        // Crossover measured on 1M x 1536: the scan takes 8 dot products per pass over the rows, the MFMA path
+        // costs a whole 128-query tile whatever the count -- 3.3 ms for fp32 rows (two scan passes), but
+        // only 0.65 ms for 16-bit rows, which is what the scan needs for four embeddings.
+        // With the split copy of an fp32 table in place its batches run on the 16-bit pipe too (6.5 ms against 8.9 ms
+        // for 8 queries on 4M x 1536).
+        const bool f32_pipe = idx->dtype == HVS_F32 && !(idx->split && idx->split_n == idx->n && !getenv("HVS_NO_SPLIT"));
+        int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
+        // A large fp32 table with a current split copy, small k, no WHERE: even one query is better off on the filter
+        // route -- the ring kernel streams the hi slabs, half the bytes the scan has to read, and the candidates are
+        // scored exactly afterwards (10M x 1536: 5.8 ms for up to 64 queries against 8.9 ms for one scan pass).  End to
+        // end the routes cross at about 1.5 GB of fp32 rows (1536 columns: 0.35 / 0.37 ms at 262 144 rows, 0.48 / 0.61 ms
+        // at 524 288, 0.74 / 1.05 ms at 1M); from 2 GB on the filter route is taken.
+        int64_t filter_min_rows = ((int64_t)500 * 1000 * 1000 + idx->ld - 1) / idx->ld;
+        if (const char *e = getenv("HVS_FILTER_MIN_ROWS")) filter_min_rows = atoll(e);
+        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 64 && group_filter < 0 && !d_mask && row_end - row_begin >= filter_min_rows &&
+            !getenv("HVS_NO_FILTER"))
+            crossover = 1;
+        use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);
+    }
+    if (row_end == row_begin) {
+        // empty range: counts 0, +inf / -1 entries
+        use_mfma = false;
+    }
+    if (use_mfma) {
+        // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy if it exists or from 16 embeddings on
+        const int split_mode = algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_AUTO ? 2 : 1);
+        // ... and where the split copy is in use, small k first tries one product instead of three: a filter pass over
+        // the hi slabs alone, then exact fp32 scores of its candidates (MFMA_SPLIT keeps the three products)
+        bool done = false;
+        if (idx->dtype == HVS_F32 && (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_AUTO) &&
+            (algo == HVS_ALGO_MFMA || nq_total >= 16 || (idx->split && idx->split_n == idx->n)))
+            HVS_TRY(hvs_search_rescore(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids,
+                                       d_count, &done));
+        if (!done)
+            HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                    split_mode));
+    } else
+        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                nullptr, 0));
+
+    return 0;
+}
+
+// out = the k smallest of two ascending (distance, row position) lists per query, positions mapped to ids.  One block
+// per query; an entry's place in the union is its own index plus the entries of the other list ordered before it
+// (positions are distinct, so no two entries compare equal).
+__global__ __launch_bounds__(256) void merge_two_kernel(const float *__restrict__ da, const int64_t *__restrict__ pa, const int32_t *__restrict__ ca,
+                                                         const float *__restrict__ db, const int64_t *__restrict__ pb, const int32_t *__restrict__ cb,
+                                                         int k, const int64_t *__restrict__ ids, float *__restrict__ od, int64_t *__restrict__ oi,
+                                                         int32_t *__restrict__ oc) {
+    const int q = blockIdx.x;
+    const int na = ca[q], nb = cb[q];
+    const float *A = da + (size_t)q * k, *B = db + (size_t)q * k;
+    const int64_t *PA = pa + (size_t)q * k, *PB = pb + (size_t)q * k;
+    for (int t = threadIdx.x; t < na + nb; t += blockDim.x) {
+        const bool from_a = t < na;
+        const int i = from_a ? t : t - na;
+        const float d = from_a ? A[i] : B[i];
+        const int64_t p = from_a ? PA[i] : PB[i];
+        const float *O = from_a ? B : A;
+        const int64_t *PO = from_a ? PB : PA;
+        int lo = 0, hi = from_a ? nb : na;  // entries of the other list ordered before (d, p)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (O[mid] < d || (O[mid] == d && PO[mid] < p)) lo = mid + 1;
+            else hi = mid;
+        }
+        const int rank = i + lo;
+        if (rank < k) {
+            od[(size_t)q * k + rank] = d;
+            oi[(size_t)q * k + rank] = ids[p];
+        }
+    }
+    const int total = na + nb < k ? na + nb : k;
+    for (int t = total + threadIdx.x; t < k; t += blockDim.x) {
+        od[(size_t)q * k + t] = __builtin_inff();
+        oi[(size_t)q * k + t] = -1;
+    }
+    if (threadIdx.x == 0) oc[q] = total;
+}
+
 int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter, const uint32_t *row_mask,
                     bool mask_on_device, double max_distance, int64_t row_begin, int64_t row_end, float *out_dist, int64_t *out_ids,
                     int32_t *out_count, int on_device, int algo) {
@@ -892,50 +985,39 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
         }
     }
 
-    bool use_mfma = false;
-    if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32 || algo == HVS_ALGO_MFMA_SPLIT) {
-        HVS_REQUIRE(hvs_mfma_supported(idx, nq, fold, k), "hvs_search: the MFMA path does not support this shape (dtype %d, dim %d, fold %d, k %d)", idx->dtype, idx->dim, fold, k);
-        use_mfma = true;
-    } else if (algo == HVS_ALGO_AUTO) {
-        // Crossover measured on 1M x 1536: the scan takes 8 dot products per pass over the rows, the MFMA path
-        // costs a whole 128-query tile whatever the count -- 3.3 ms for fp32 rows (two scan passes), but
-        // only 0.65 ms for 16-bit rows, which is what the scan needs for four embeddings.
-        // With the split copy of an fp32 table in place its batches run on the 16-bit pipe too (6.5 ms against 8.9 ms
-        // for 8 queries on 4M x 1536).
-        const bool f32_pipe = idx->dtype == HVS_F32 && !(idx->split && idx->split_n == idx->n && !getenv("HVS_NO_SPLIT"));
-        int crossover = f32_pipe ? 16 : 5;  // 16-bit pipe: four embeddings are one scan pass (2.0 ms on 4M x 1536 f16), five are two (3.9 ms vs 2.2 ms)
-        // A large fp32 table with a current split copy, small k, no WHERE: even one query is better off on the filter
-        // route -- the ring kernel streams the hi slabs, half the bytes the scan has to read, and the candidates are
-        // scored exactly afterwards (10M x 1536: 5.8 ms for up to 64 queries against 8.9 ms for one scan pass).  End to
-        // end the routes cross at about 1.5 GB of fp32 rows (1536 columns: 0.35 / 0.37 ms at 262 144 rows, 0.48 / 0.61 ms
-        // at 524 288, 0.74 / 1.05 ms at 1M); from 2 GB on the filter route is taken.
-        int64_t filter_min_rows = ((int64_t)500 * 1000 * 1000 + idx->ld - 1) / idx->ld;
-        if (const char *e = getenv("HVS_FILTER_MIN_ROWS")) filter_min_rows = atoll(e);
-        if (idx->dtype == HVS_F32 && !f32_pipe && k <= 64 && group_filter < 0 && !row_mask && row_end - row_begin >= filter_min_rows &&
-            !getenv("HVS_NO_FILTER"))
-            crossover = 1;
-        use_mfma = nq_total >= crossover && hvs_mfma_supported(idx, nq, fold, k);
-    }
-    if (row_end == row_begin) {
-        // empty range: counts 0, +inf / -1 entries
-        use_mfma = false;
-    }
-    if (use_mfma) {
-        // fp32 rows: 0 = fp32 MFMA kernel, 1 = split copy (built if need be), 2 = split copy if it exists or from 16 embeddings on
-        const int split_mode = algo == HVS_ALGO_MFMA_F32 ? 0 : (algo == HVS_ALGO_AUTO ? 2 : 1);
-        // ... and where the split copy is in use, small k first tries one product instead of three: a filter pass over
-        // the hi slabs alone, then exact fp32 scores of its candidates (MFMA_SPLIT keeps the three products)
-        bool done = false;
-        if (idx->dtype == HVS_F32 && (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_AUTO) &&
-            (algo == HVS_ALGO_MFMA || nq_total >= 16 || (idx->split && idx->split_n == idx->n)))
-            HVS_TRY(hvs_search_rescore(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids,
-                                       d_count, &done));
-        if (!done)
-            HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
-                                    split_mode));
+    // A table in group order (hvs_index_partition) answers a group filter with a row range: the ordered part holds the
+    // group's rows in [gb, ge), searched with no code test; rows added since form a tail that keeps the per-row test.
+    int64_t gb = 0, ge = 0;
+    if (group_filter >= 0 && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, group_filter, &gb, &ge)) {
+        const int64_t mb = row_begin > gb ? row_begin : gb, me = row_end < ge ? row_end : ge;
+        const int64_t tb = row_begin > idx->part_n ? row_begin : idx->part_n, te = row_end;
+        const bool have_main = mb < me, have_tail = tb < te;
+        if (have_main && have_tail) {
+            // both: each into lists of row positions, then one merge by (distance, position) -- the ordered part lies
+            // below the tail, so ties still go to the lower position
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t o_i = up(dist_bytes), o_c = o_i + up(ids_bytes), one = o_c + up(cnt_bytes);
+            void *pair = nullptr;
+            HVS_TRY(hvs_ws_get(idx, 10, 2 * one, &pair));
+            char *a = (char *)pair, *b = a + one;
+            idx->emit_positions = true;
+            int rc = search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, (float *)a, (int64_t *)(a + o_i), (int32_t *)(a + o_c), algo);
+            if (rc == 0)
+                rc = search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, tb, te, (float *)b, (int64_t *)(b + o_i),
+                                  (int32_t *)(b + o_c), algo);
+            idx->emit_positions = false;
+            HVS_TRY(rc);
+            HVS_TRY(hvs_prof_begin(idx));
+            merge_two_kernel<<<nq, 256, 0, idx->stream>>>((const float *)a, (const int64_t *)(a + o_i), (const int32_t *)(a + o_c), (const float *)b,
+                                                         (const int64_t *)(b + o_i), (const int32_t *)(b + o_c), k, idx->ids, d_dist, d_ids, d_count);
+            HVS_HIP(hipGetLastError());
+            HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
+        } else if (have_tail)
+            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, tb, te, d_dist, d_ids, d_count, algo));
+        else  // the group's range alone (an empty one gives counts of 0)
+            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, have_main ? me : mb, d_dist, d_ids, d_count, algo));
     } else
-        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
-                                nullptr, 0));
+        HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, algo));
 
     if (!on_device) {
         const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
@@ -1010,6 +1092,15 @@ extern "C" int hvs_search_noalloc(hvs_index *idx, const float *queries, int nq, 
     float *d_q = (float *)scratch, *d_qinv = (float *)(scratch + inv_off);
     prep_queries_kernel<<<(nq_total + 3) / 4, 256, 0, idx->stream>>>(queries, d_q, d_qinv, nq_total, idx->dim, idx->ld, idx->dtype);
     HVS_HIP(hipGetLastError());
+    // a table in group order: the group's row range in place of the per-row test, when no rows have arrived since
+    // (a tail would need a second pass and a merge, whose lists this call has no room for)
+    int64_t gb = 0, ge = 0;
+    if (group_filter >= 0 && idx->part_n >= row_end && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, group_filter, &gb, &ge)) {
+        row_begin = row_begin > gb ? row_begin : gb;
+        row_end = row_end < ge ? row_end : ge;
+        if (row_begin > row_end) row_begin = row_end;
+        group_filter = -1;
+    }
     // every wave of the scan writes all k keys of its list and every merge level writes all of its outputs, so nothing
     // in the array has to start at zero: what the previous call left is overwritten before it is read
     return hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, row_mask, hvs_ceil_to_float(max_distance), row_begin, row_end,
@@ -1141,12 +1232,25 @@ int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_
     if (row_end < 0 || row_end > idx->n) row_end = idx->n;
     if (row_begin < 0) row_begin = 0;
     int64_t total = 0;
-    if (row_begin < row_end) {
+    // a table in group order: the group's row range (no code test), then the rows added since (with it); both in
+    // ascending row position, the range below the tail
+    struct Seg { int64_t b, e; int32_t gf; } segs[2];
+    int n_segs = 0;
+    int64_t gb = 0, ge = 0;
+    if (group_filter >= 0 && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, group_filter, &gb, &ge)) {
+        const int64_t mb = row_begin > gb ? row_begin : gb, me = row_end < ge ? row_end : ge;
+        const int64_t tb = row_begin > idx->part_n ? row_begin : idx->part_n;
+        if (mb < me) segs[n_segs++] = {mb, me, -1};
+        if (tb < row_end) segs[n_segs++] = {tb, row_end, group_filter};
+    } else if (row_begin < row_end)
+        segs[n_segs++] = {row_begin, row_end, group_filter};
+    if (n_segs > 0) {
         HVS_HIP(hipSetDevice(idx->device));
-        const int64_t n_rows = row_end - row_begin;
+        int64_t widest = 0;
+        for (int i = 0; i < n_segs; i++) widest = segs[i].e - segs[i].b > widest ? segs[i].e - segs[i].b : widest;
         // staging (workspace 3): [distance column][mask words, if they come from the host][outputs, if they go to the host]
         const size_t mask_bytes = (row_mask && !mask_on_device) ? (size_t)((idx->n + 31) / 32) * 4 : 0;
-        const size_t o_mask = ((size_t)n_rows * 4 + 255) & ~(size_t)255;
+        const size_t o_mask = ((size_t)widest * 4 + 255) & ~(size_t)255;
         const size_t o_dist = (o_mask + mask_bytes + 255) & ~(size_t)255;
         const size_t o_ids = (o_dist + (on_device ? 0 : (size_t)capacity * 4) + 255) & ~(size_t)255;
         void *stage = nullptr;
@@ -1157,17 +1261,22 @@ int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_
             HVS_HIP(hipMemcpyAsync((char *)stage + o_mask, row_mask, mask_bytes, hipMemcpyHostToDevice, idx->stream));
             d_mask = (const uint32_t *)((char *)stage + o_mask);
         }
-        HVS_TRY(distance_column(idx, queries, fold, on_device, row_begin, row_end, d_col, "hvs_range_search"));
-        hvs_live_params lp{idx->groups, d_mask, idx->n_deleted > 0 ? idx->deleted : nullptr, group_filter, row_begin, row_end};
-        lp.dist = d_col;
-        lp.max_dist = hvs_ceil_to_float(max_distance);
         float *d_od = on_device ? out_dist : (float *)((char *)stage + o_dist);
         int64_t *d_oi = on_device ? out_ids : (int64_t *)((char *)stage + o_ids);
-        HVS_TRY(hvs_range_collect(idx, lp, capacity, d_od, d_oi, &total));
-        const int64_t m = total < capacity ? total : capacity;
-        if (!on_device && m > 0) {
-            HVS_HIP(hipMemcpyAsync(out_dist, d_od, (size_t)m * 4, hipMemcpyDeviceToHost, idx->stream));
-            HVS_HIP(hipMemcpyAsync(out_ids, d_oi, (size_t)m * 8, hipMemcpyDeviceToHost, idx->stream));
+        int64_t written = 0;
+        for (int i = 0; i < n_segs; i++) {
+            HVS_TRY(distance_column(idx, queries, fold, on_device, segs[i].b, segs[i].e, d_col, "hvs_range_search"));
+            hvs_live_params lp{idx->groups, d_mask, idx->n_deleted > 0 ? idx->deleted : nullptr, segs[i].gf, segs[i].b, segs[i].e};
+            lp.dist = d_col;
+            lp.max_dist = hvs_ceil_to_float(max_distance);
+            int64_t seg_total = 0;
+            HVS_TRY(hvs_range_collect(idx, lp, capacity - written, d_od + written, d_oi + written, &seg_total));
+            total += seg_total;
+            written += seg_total < capacity - written ? seg_total : capacity - written;
+        }
+        if (!on_device && written > 0) {
+            HVS_HIP(hipMemcpyAsync(out_dist, d_od, (size_t)written * 4, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipMemcpyAsync(out_ids, d_oi, (size_t)written * 8, hipMemcpyDeviceToHost, idx->stream));
         }
         HVS_HIP(hipStreamSynchronize(idx->stream));
     }

@@ -420,6 +420,38 @@ class HvsIndex:
             check(self._lib.hvs_index_compact(self._h, 1 if renumber_ids else 0, ctypes.byref(n)))
         return n.value
 
+    def partition(self, renumber_ids: bool = False) -> np.ndarray:
+        """Order the rows by group code (deleted rows are dropped, rows of one code keep their order), so that a search
+        with a group filter scans that group's row range and nothing else (``hvs_index_partition``).  Returns, for
+        every new row position, the position the row had.  Ids travel with their rows, or become the new positions
+        when ``renumber_ids`` is set.  Rows added afterwards are searched with the per-row test until the next call."""
+        with self._lock:
+            old = np.empty(len(self), dtype=np.int64)
+            n = ctypes.c_int64(0)
+            check(self._lib.hvs_index_partition(self._h, 1 if renumber_ids else 0, ctypes.byref(n), _np_ptr(old)))
+        return old[: n.value]
+
+    def partition_info(self) -> Tuple[int, int]:
+        """``(rows at the front of the table that are in group order, distinct group codes among them)``; (0, 0) for a
+        table that was never partitioned."""
+        rows, groups = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(self._lib.hvs_index_partition_info(self._h, ctypes.byref(rows), ctypes.byref(groups)))
+        return rows.value, groups.value
+
+    def set_ids(self, first: int, ids) -> None:
+        """Overwrite the external ids of rows ``[first, first + len(ids))``."""
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        with self._lock:
+            check(self._lib.hvs_index_set_ids(self._h, int(first), len(a), _np_ptr(a)))
+
+    def ids(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """External ids of rows ``[first, first + n)``."""
+        n = len(self) - first if n is None else int(n)
+        out = np.empty(n, dtype=np.int64)
+        with self._lock:
+            check(self._lib.hvs_index_export(self._h, int(first), n, None, _np_ptr(out), None, None))
+        return out
+
     def export(self, first: int = 0, n: Optional[int] = None):
         """Rows ``[first, first + n)`` as stored -> ``(rows, ids, group_codes, deleted)``; ``rows`` is
         float32 / float16, or uint16 bit patterns for a bf16 index."""

@@ -117,6 +117,29 @@ int hvs_index_deleted_count(hvs_index *idx, int64_t *out_rows);
 int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
 
 /*
+ * Order the rows by group code, so that the WHERE workspaceId = .. AND knowledgeBaseId = .. every PGVector.query
+ * carries (pgvector.py:577-580) selects a row range instead of a test per row: deleted rows are dropped as by
+ * hvs_index_compact, the live rows are sorted by their group code (codes must be >= 0), rows of one code keep their
+ * order, and the table remembers code -> [begin, end).  From then on a search, range search or distance filter with
+ * group_filter >= 0 runs over that range with no code test, no live-row count and no copy; rows added afterwards form
+ * a tail that is searched with the per-row test and merged in, until the next call orders them too.  Answers are the
+ * same as before the call (ids travel with their rows; ties in distance still go to the lower row position, which
+ * for rows of one group is the order they had).  Row positions change: out_old_positions (HOST array with room for
+ * the row count before the call, or NULL) receives, for every new position, the position the row had.  renumber_ids:
+ * ids become the new positions.  *out_rows (may be NULL) = the row count afterwards.  The rows move through new
+ * arrays: the call needs as much free device memory as the table holds and fails, leaving the table as it was, when
+ * that is not there.  Nearest thing in the reference: none (PostgreSQL would answer the same WHERE through a b-tree on
+ * the two columns, which the reference does not declare either); the step is CLUSTER for the HBM-resident table.
+ */
+int hvs_index_partition(hvs_index *idx, int renumber_ids, int64_t *out_rows, int64_t *out_old_positions);
+/* rows at the front of the table that are in group order (0: no partition) and the number of distinct codes among them */
+int hvs_index_partition_info(hvs_index *idx, int64_t *ordered_rows, int64_t *n_groups);
+
+/* Overwrite the external ids of row positions [first_pos, first_pos + n) from a HOST array (after a compaction or
+ * partition whose caller keeps its own numbering of the rows).  No reference counterpart. */
+int hvs_index_set_ids(hvs_index *idx, int64_t first_pos, int64_t n, const int64_t *ids);
+
+/*
  * Bring the search-side copy of an fp32 table up to date ahead of the first search (it is otherwise built by the
  * first batched search): the [hi | lo] fp16 split copy that batched searches contract and that searches with
  * k <= 128 (single queries on large tables: k <= 64) use as a filter before exact fp32 scoring.  The nearest
@@ -197,8 +220,9 @@ int hvs_search(hvs_index *idx, const float *queries, int nq, int fold, int k,
  * The WHERE clauses of PGVector.query beyond the (workspaceId, knowledgeBaseId) pair (pgvector.py:573-580), evaluated on
  * the GPU: every row carries four attributes next to its group code -- workspace code, knowledge-base code, uri code
  * (int32 each) and a private flag -- set with hvs_index_set_attributes after the rows were added (HOST arrays of n
- * entries for row positions [first_pos, first_pos + n); a NULL array leaves that attribute as it is, attributes never
- * set read as 0; they move with their rows in hvs_index_compact).  An hvs_filter names the values a row must have;
+ * entries for row positions [first_pos, first_pos + n); a NULL array leaves that attribute as it is, an attribute no
+ * call has set reads -1 and satisfies no clause, so rows between hvs_index_add and this call pass no attribute filter;
+ * attributes move with their rows in hvs_index_compact / hvs_index_partition).  An hvs_filter names the values a row must have;
  * the searches below evaluate it in one pass over the attribute columns (16 B per row) into a row bitmask on the
  * device and then run as hvs_search / hvs_range_search do with that mask: no per-query mask is built or uploaded by the
  * host.  The uri list is a HOST array of at most HVS_MAX_FILTER_URIS codes in any order.
