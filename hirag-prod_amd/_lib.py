@@ -13,7 +13,8 @@ import sys
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libhvs.so")
+# HVS_LIB: another build of the same library (experiments: a build with the kernels' timing hooks, `make HOOKS=1`)
+LIB_PATH = os.environ.get("HVS_LIB") or os.path.join(HERE, "csrc", "libhvs.so")
 
 HVS_F32, HVS_F16, HVS_BF16 = 0, 1, 2
 HVS_ALGO_AUTO, HVS_ALGO_SCAN, HVS_ALGO_MFMA, HVS_ALGO_MFMA_F32, HVS_ALGO_MFMA_SPLIT = 0, 1, 2, 3, 4

@@ -54,6 +54,11 @@ struct SearchParams {
     int split_steps;  // 0: plain operands.  > 0: both operands hold rows [hi slab | lo slab] of split_steps k-steps each
                       // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
     unsigned int *lockstep;  // optional: one arrival counter per (XCD, corpus split) -- see lockstep_arrive; zeroed before the launch
+    // optional (kernels built with XCHG): the blocks of a query tile pool what their first corpus tile shows -- see exchange_bound
+    uint32_t *xchg_min;       // [nq_out][S * WN] ordered images of the smallest distance per (block, wave column); all ones before the launch
+    uint32_t *xchg_tau;       // [nq_out] float bits of the bound derived from them; all ones (a NaN) before the launch
+    unsigned int *pooled_count;  // optional (kernels built with XCHG): [nq_out] keys in a query's pooled list, zeroed before the launch;
+                                 // `partial` then holds one list of S * k slots per query that every block appends its survivors to
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
                     // 512 per-phase cycle counts printed to stderr
 };
@@ -281,7 +286,7 @@ __device__ __forceinline__ void tile_epilogue(const SearchParams &p, const Block
     // of the 16 bounds -- one v_max3 chain, one multiply, one compare per tile; it is used once the block has
     // seen enough rows for most tiles to hold no survivor (about k / rows_seen of the scores survive).
     // Level 2, per group of four scores (four adjacent queries): the test proper.
-    const bool level1 = p.tau0 != nullptr || (int64_t)p.k * 512 < (tile - tile_first) * T::BN;
+    const bool level1 = p.tau0 != nullptr || p.xchg_min != nullptr || (int64_t)p.k * 512 < (tile - tile_first) * T::BN;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         f32x4 bnd[4];
@@ -393,7 +398,14 @@ __device__ __forceinline__ void publish_lists_kl(const SearchParams &p, const Bl
             const int i = e * 64 + lane;
             a[e] = i < c ? arr[i] : HVS_KEY_EMPTY;
         }
-        bitonic_sort<KL>(a, lane);
+        // with a good starting bound most lists of a short stream hold a handful of keys: one key per lane sorts in a
+        // sixth of the steps of the full network, an empty or single-key list needs none
+        if (c > 64) bitonic_sort<KL>(a, lane);
+        else if (c > 1) {
+            uint64_t a1[1] = {a[0]};
+            bitonic_sort<1>(a1, lane);
+            a[0] = a1[0];
+        }
         uint64_t *dst = p.partial + ((size_t)qo * p.S + s) * p.k;
 #pragma unroll
         for (int e = 0; e < KL; e++) {
@@ -408,6 +420,252 @@ template <int FOLD, class T>
 __device__ __forceinline__ void publish_lists(const SearchParams &p, const BlockState &b, int q_out0, int s, int wave, int lane) {
     if (p.k <= 128) publish_lists_kl<FOLD, T, 2>(p, b, q_out0, s, wave, lane);
     else publish_lists_kl<FOLD, T, MFMA_MAX_K / 64>(p, b, q_out0, s, wave, lane);
+}
+
+// ---- a bound every block starts from, pooled from the first corpus tile of all blocks ----------------------------
+// A block tightens tau from the rows it has seen itself.  When a table (or the row range a group filter selects) is cut
+// into so many splits that a block sees only a few tiles, tau never gets anywhere: every score is a survivor, every
+// array is ranked after every tile, and the selection costs several times the contraction (256 queries x 195 k rows of
+// 768 bf16, k = 100: 0.62 ms, of which the K loops are 18 %).  All blocks of a launch are resident at once (the grid is
+// sized to the chip), so they can pool what their FIRST tile shows before any of them runs its epilogue:
+//   1. every wave forms, per query, the smallest distance over its rows of the tile (a min over the accumulator
+//      registers of a lane and over the 32 lanes of a half: no candidate array, no ranking) and publishes it;
+//   2. the S x WN published values of a query stand for disjoint sets of rows, so their k-th smallest bounds the
+//      k-th distance of the whole table from above -- one wave per query finds it (bitwise search, as cand_kth does)
+//      and publishes the smallest float above it; the queries of a tile are dealt round-robin to the tile's S blocks;
+//   3. every block starts its first epilogue from min(thr, that bound): with 256 blocks of 256 rows the bound sits
+//      near the k / 65 536 quantile instead of +inf.
+// The accumulators of the first tile stay in registers across the two waits.  Both waits are bounded (blocks of
+// another kernel may hold CUs): a block that gives up goes on with what is published so far -- slots nobody has
+// filled read as +inf / NaN, so whatever a block derives is still an upper bound, and with nothing it keeps thr.
+// What is exchanged travels in agent-scope atomics, which are performed where all XCDs see them, and there are no
+// arrival counters: a slot nobody has filled yet reads all ones, which no published value is, so a reader simply looks
+// again (a bounded number of times -- blocks of another kernel may hold CUs -- after which it goes on with what is there).
+#define XCHG_SPINS 400
+// vals[i * stride] for i < m: the k-th smallest, all ones when fewer than k are there
+template <int R> __device__ __forceinline__ uint32_t xchg_kth(const uint32_t *vals, int64_t stride, int m, int k, int lane) {
+    uint32_t own[R];
+    for (int spin = 0; spin < XCHG_SPINS; spin++) {
+        bool missing = false;
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            const int i = e * 64 + lane;
+            own[e] = i < m ? __hip_atomic_load(vals + (size_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            missing |= own[e] == 0xFFFFFFFFu;
+        }
+        if (!__ballot(missing)) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int e = 0; e < R; e++)
+        if (e * 64 + lane >= m) own[e] = 0xFFFFFFFFu;
+    uint32_t t = 0;  // the smallest T with #{value <= T} >= k
+    for (int bit = 31; bit >= 0; bit--) {
+        const uint32_t trial = t | ((1u << bit) - 1u);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < R; e++) c += __popcll(__ballot(own[e] <= trial));
+        if (c < k) t |= 1u << bit;
+    }
+    return t;
+}
+
+// max over the 32 lanes of a wave half, left in the half's last lane (31 / 63): four row_shr steps inside each row of 16
+// lanes, then row_bcast:15 hands row 0's result to row 1 (and row 2's to row 3).  A lane without a source keeps its own.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_max_step(float v) {
+    const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return fmaxf(v, __int_as_float(o));
+}
+__device__ __forceinline__ float half_max(float v) {
+    v = dpp_max_step<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xF>(v);  // row_shr:8
+    v = dpp_max_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
+// scratch: T::WN * T::BM floats of LDS nobody else uses until the next block barrier after the call
+template <int FOLD, class T>
+__device__ __forceinline__ void exchange_bound(const SearchParams &p, const BlockState &b, const f32x16 (&acc)[T::MT][T::NT],
+                                               const float (&invn2)[T::NT], float *scratch, int qt, int s, int64_t a_row0, int wm, int wn,
+                                               int lane, int wave, int tid) {
+    constexpr int MT = T::MT, NT = T::NT, BMQ = T::BM / FOLD;
+    const int h = lane >> 5;
+    const int M = p.S * T::WN;
+    const int64_t q0 = a_row0 / FOLD;
+    __syncthreads();  // every wave is done with the fragments of the stage that now serves as scratch
+    // 1. smallest distance per query over this wave's rows of the tile -> scratch[wn][query of the tile].  The distance
+    //    falls as dot / |row| grows and 1/|q| is a positive factor, so the largest dot / |row| over the rows is taken first
+    //    (one multiply per score, a max over the lane's rows, five DPP steps over the 32 lanes of a half: lanes 31 and 63
+    //    end up with it) and turned into a distance once; a NaN (filtered row, zero norm) drops out of every max.
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const int a_loc = wm * (MT * 32) + mt * 32 + 8 * gq + 4 * h;
+            const f32x4 qi = *reinterpret_cast<const f32x4 *>(b.qinv + a_loc);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) m = fmaxf(m, acc[mt][nt][4 * gq + e] * invn2[nt]);
+                m = half_max(m);
+                v[e] = hvs_cos_dist(m, 1.0f, qi[e]);  // (m * 1) * 1/|q|: the value the epilogue forms for that row
+            }
+            if (FOLD == 2) {
+                v[0] = fminf(v[0], v[1]);
+                v[2] = fminf(v[2], v[3]);
+            } else if (FOLD == 4) {
+                v[0] = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+            }
+            if ((lane & 31) == 31) {
+#pragma unroll
+                for (int e = 0; e < 4; e += FOLD) scratch[wn * BMQ + (a_loc + e) / FOLD] = v[e];
+            }
+        }
+    }
+    __syncthreads();
+    // the block's WN x BMQ values, consecutive queries in consecutive lanes: xchg_min[(s * WN + wn)][query]
+    for (int i = tid; i < T::WN * BMQ; i += T::GT) {
+        const int w = i / BMQ, ql = i - w * BMQ;
+        if (q0 + ql < p.nq_out)
+            __hip_atomic_store(p.xchg_min + (size_t)(s * T::WN + w) * p.nq_out + q0 + ql, hvs_ord(scratch[i]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // 2. this block's share of the tile's queries: the k-th smallest of the M published values, as soon as they are there
+    for (int ql = s + wave * p.S; ql < BMQ; ql += T::NW * p.S) {
+        const int64_t qo = q0 + ql;
+        if (qo >= p.nq_out) break;
+        const uint32_t *vals = p.xchg_min + qo;
+        uint32_t t;
+        if (M <= 64) t = xchg_kth<1>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 128) t = xchg_kth<2>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 256) t = xchg_kth<4>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 512) t = xchg_kth<8>(vals, p.nq_out, M, p.k, lane);
+        else t = xchg_kth<16>(vals, p.nq_out, M, p.k, lane);
+        if (lane == 0) {
+            float bound = __builtin_nanf("");  // (0x7FC00000: not the all-ones of an unfilled slot)
+            if (t < hvs_ord(INFINITY)) {
+                const float d = hvs_unord(t);  // admission is strict: the smallest float above the k-th value
+                bound = d == 0.0f ? 1.4e-45f : (d > 0.0f ? __uint_as_float(__float_as_uint(d) + 1u) : __uint_as_float(__float_as_uint(d) - 1u));
+            }
+            __hip_atomic_store(p.xchg_tau + qo, __float_as_uint(bound), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // 3. every query of the tile starts from its bound, as soon as that is there
+    for (int i = tid; i < BMQ; i += T::GT) {
+        if (q0 + i >= p.nq_out) continue;
+        uint32_t bits = 0xFFFFFFFFu;
+        for (int spin = 0; spin < XCHG_SPINS; spin++) {
+            bits = __hip_atomic_load(p.xchg_tau + q0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits != 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const float t = __uint_as_float(bits);
+        if (t < b.tau[i]) b.tau[i] = t;  // false for a NaN (fewer than k values, or a slot nobody filled in time)
+    }
+    __syncthreads();
+    for (int i = tid; i < T::BM; i += T::GT)
+        if (a_row0 + i < p.nA && b.tau[i / FOLD] < p.thr) b.bound[i] = prefilter_bound(b.tau[i / FOLD], b.qinv[i]);
+    __syncthreads();
+}
+
+// The other half of a short-stream launch: with a bound from the pooled first tiles a block ends up with a handful of
+// survivors per query, and sorting and merging S lists of k slots each per query costs more than the contraction (256
+// queries x 195 k rows, k = 100: 65 us of sorting inside the kernel and three merge launches, against 80 us of K loops).
+// Every block instead appends what it holds to ONE list per query (an atomic counter hands out the slots; a lane per
+// query does the copying, so a wave publishes 64 queries at a time), and select_pooled_kernel ranks each list once.
+// The order of a pooled list depends on timing, its contents do not, and the answer is its k smallest keys in order.
+template <int FOLD, class T>
+__device__ __forceinline__ void publish_pooled(const SearchParams &p, const BlockState &b, int q_out0, int wave, int lane) {
+    constexpr int BMQ = T::BM / FOLD;
+    const size_t slots = (size_t)p.S * p.k;
+    for (int base = wave * 64; base < BMQ; base += T::NW * 64) {
+        const int ql = base + lane;
+        const int64_t qo = (int64_t)q_out0 + ql;
+        const bool valid = ql < BMQ && qo < p.nq_out;
+        int c = valid ? b.cnt[ql] : 0;
+        c = c > p.cap ? p.cap : c;
+        uint64_t longer = __ballot(c > p.k);  // rare: an array that grew past k since its last ranking
+        while (longer) {
+            const int src = __ffsll((unsigned long long)longer) - 1;
+            longer &= longer - 1;
+            cand_reduce(b.my_cand + (size_t)(base + src) * p.cap, __shfl(c, src), p.k, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the rankings' stores before the reloads below
+        c = c > p.k ? p.k : c;
+        unsigned int at = 0;
+        if (c > 0) at = atomicAdd(p.pooled_count + qo, (unsigned int)c);
+        const uint64_t *arr = b.my_cand + (size_t)ql * p.cap;
+        uint64_t *dst = p.partial + (size_t)qo * slots + at;
+        for (int j = 0; __ballot(j < c); j++) {
+            if (j < c) {
+                uint64_t key = arr[j];
+                if (p.remap) key = (key & 0xFFFFFFFF00000000ull) | p.remap[(uint32_t)key];  // rows of a dense copy -> table positions
+                dst[j] = key;
+            }
+        }
+    }
+}
+
+// One wave per query: the k smallest keys of its pooled list, ascending, as distances / ids / count.  Lists of up to
+// 1024 keys are ranked in registers in one go; longer ones in rounds that carry the best k so far at the list's front.
+template <int KL>
+__global__ __launch_bounds__(64) void select_pooled_kernel(uint64_t *__restrict__ lists, const unsigned int *__restrict__ counts, size_t slots,
+                                                            int k, const int64_t *__restrict__ ids, float *__restrict__ out_dist,
+                                                            int64_t *__restrict__ out_ids, int32_t *__restrict__ out_count) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    uint64_t *list = lists + (size_t)q * slots;
+    size_t n = counts[q];
+    n = n > slots ? slots : n;
+    int have = 0;      // keys at the list's front that are the best of everything read so far
+    size_t pos = 0;    // next unread key
+    while (pos < n) {
+        constexpr int ROUND = CAND_MAX;
+        const int take = (int)((n - pos) < (size_t)(ROUND - have) ? (n - pos) : (size_t)(ROUND - have));
+        const int cnt = have + take;
+        if (cnt > k) {
+            uint64_t own[ROUND / 64];
+#pragma unroll
+            for (int e = 0; e < ROUND / 64; e++) {
+                const int i = e * 64 + lane;
+                own[e] = i < have ? list[i] : (i < cnt ? list[pos + (i - have)] : HVS_KEY_EMPTY);
+            }
+            const uint64_t kth = cand_kth<ROUND / 64>(own, k);
+            cand_keep<ROUND / 64>(own, kth, list, lane);
+            have = k;
+        } else {
+            if (pos != (size_t)have)  // (only the first round can end here: have = 0, pos = 0)
+                for (int i = lane; i < take; i += 64) list[have + i] = list[pos + i];
+            have = cnt;
+        }
+        pos += take;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    uint64_t a[KL];
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        a[e] = i < have ? list[i] : HVS_KEY_EMPTY;
+    }
+    if (have > 64 || KL == 1) bitonic_sort<KL>(a, lane);
+    else {
+        uint64_t a1[1] = {a[0]};
+        bitonic_sort<1>(a1, lane);
+        a[0] = a1[0];
+    }
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        if (i < k) {
+            const bool real = a[e] != HVS_KEY_EMPTY;
+            out_dist[(size_t)q * k + i] = real ? hvs_unord((uint32_t)(a[e] >> 32)) : __builtin_inff();
+            out_ids[(size_t)q * k + i] = real ? (ids ? ids[(uint32_t)a[e]] : (int64_t)(uint32_t)a[e]) : -1;
+        }
+    }
+    if (lane == 0) out_count[q] = have;
 }
 
 // LDS layout: [2 stages][tau][cnt][qinv][bound]
@@ -430,7 +688,7 @@ template <class T> __device__ __forceinline__ BlockState block_state(char *smem,
 #define HVS_HOOK(p) 0
 #endif
 
-template <int DT, int FOLD, class T>
+template <int DT, int FOLD, class T, bool XCHG = false>
 __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kernel(SearchParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device-only types (buffer descriptors) inside
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -481,7 +739,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
     // in the inner loop, the tile's last step (whose LDS-DMA fetches step 0 of the next tile) is written out after it.
     int cur = 0;
 #ifdef HVS_KERNEL_HOOKS
-    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_last = (p.dbg & 512) ? clock64() : 0;
+    unsigned long long pr_loop = 0, pr_epi = 0, pr_bar = 0, pr_cmp = 0, pr_x = 0, pr_last = (p.dbg & 512) ? clock64() : 0;
 #endif
     for (int64_t tile = tile_lo; tile < tile_hi; tile++) {
         load_row_meta<T>(p, tile, wn, lane, invn2);
@@ -502,6 +760,16 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         unsigned long long c1 = 0, c2 = 0, c3 = 0;
         if (prof) c1 = clock64();
 #endif
+        if (XCHG && tile == tile_lo) {
+            exchange_bound<FOLD, T>(p, b, acc, invn2, reinterpret_cast<float *>(stages + cur * STAGE_BYTES), qt, s, a_row0, wm, wn, lane, wave, tid);
+#ifdef HVS_KERNEL_HOOKS
+            if (prof) {
+                const unsigned long long cx = clock64();
+                pr_x += cx - c1;
+                c1 = cx;
+            }
+#endif
+        }
         if (!(HVS_HOOK(p) & 8)) tile_epilogue<FOLD, T, DT != HVS_F32>(p, b, acc, invn2, tile, tile_lo, wm, wn, lane);
         zero_acc(acc);
 #ifdef HVS_KERNEL_HOOKS
@@ -533,10 +801,16 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         atomicAdd(&p.prof[1], pr_epi);
         atomicAdd(&p.prof[2], pr_bar);
         atomicAdd(&p.prof[3], pr_cmp);
+        atomicAdd(&p.prof[4], pr_x);
     }
+    const unsigned long long c_pub = (p.dbg & 512) ? clock64() : 0;
 #endif
     __syncthreads();
-    publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
+    if (XCHG && p.pooled_count) publish_pooled<FOLD, T>(p, b, qt * (BM / FOLD), wave, lane);
+    else publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
+#ifdef HVS_KERNEL_HOOKS
+    if ((p.dbg & 512) && lane == 0) atomicAdd(&p.prof[5], clock64() - c_pub);
+#endif
 #endif
 }
 
@@ -921,14 +1195,14 @@ __global__ void tau_from_topk_kernel(const float *__restrict__ dist, const int32
     tau0[q] = t;
 }
 
-template <int DT, class T>
+template <int DT, class T, bool XCHG = false>
 static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p) {
     const size_t lds = search_lds_bytes<T>();
 #define HVS_LAUNCH_SEARCH(F)                                                                                         \
     do {                                                                                                             \
-        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<DT, F, T>),                   \
+        HVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mfma_search_kernel<DT, F, T, XCHG>),             \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
-        mfma_search_kernel<DT, F, T><<<grid, T::GT, lds, st>>>(p);                                                   \
+        mfma_search_kernel<DT, F, T, XCHG><<<grid, T::GT, lds, st>>>(p);                                             \
     } while (0)
     if (pf == 1) HVS_LAUNCH_SEARCH(1);
     else if (pf == 2) HVS_LAUNCH_SEARCH(2);
@@ -1142,41 +1416,64 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
 #endif
     p.QT = stream ? 1 : (nA + bm - 1) / bm;
 
+    bool want_xchg = false;  // set below, before the main pass
+    const int slots_of_tile = stream ? 256 : (big ? 256 : (small ? 1024 : 512));  // blocks the chip holds at once
+    const int wn_of_tile = big ? Tile256::WN : (small ? Tile64::WN : Tile128::WN);
+    // corpus splits for a range of T tiles
+    auto splits_of = [&](int64_t T) -> int {
+        if (stream) return (int)(T < 256 ? T : 256);
+        // fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a multiple of 8 (XCD
+        // affinity) and every split non-empty
+        int S = (slots_of_tile + p.QT - 1) / p.QT;
+        S = (S + 7) / 8 * 8;
+        if ((int64_t)S > T) S = (int)T;
+        if (S >= 8) S = S / 8 * 8;
+        return S < 1 ? 1 : S;
+    };
+    // can the blocks of such a launch pool their first tiles (exchange_bound)?  16-bit operands on the two-stage kernel,
+    // every block resident at once, at most 1024 and at least 2 k published values per query
+    auto xchg_fits = [&](int S) -> bool {
+        return !stream && kdt != HVS_F32 && p.QT * S <= slots_of_tile && S * wn_of_tile <= 1024 && S * wn_of_tile >= 2 * k;
+    };
     // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
     auto run_pass = [&](SearchParams pp, int64_t rb, int64_t re, const float *tau0, float *o_dist, int64_t *o_ids, int32_t *o_count) -> int {
         pp.row_begin = rb;
         pp.row_end = re;
         pp.tau0 = tau0;
         pp.T = (re - rb + bn - 1) / bn;
-        int S;
-        if (stream) {
-            S = (int)(pp.T < 256 ? pp.T : 256);
-        } else {
-            // splits: fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a
-            // multiple of 8 (XCD affinity) and every split non-empty
-            const int slots = big ? 256 : (small ? 1024 : 512);
-            S = (slots + pp.QT - 1) / pp.QT;
-            S = (S + 7) / 8 * 8;
-            if ((int64_t)S > pp.T) S = (int)pp.T;
-            if (S >= 8) S = S / 8 * 8;
-            if (S < 1) S = 1;
-        }
+        const int S = splits_of(pp.T);
         pp.S = S;
         const int grid = pp.QT * S;
         void *cand = nullptr, *bufB = nullptr;
         const size_t cand_bytes = (size_t)grid * (bm / pf) * pp.cap * 8;
         const size_t part_bytes = (size_t)nq * S * k * 8;
         const int P2 = (S + MERGE_FAN - 1) / MERGE_FAN;
+        const int slots = slots_of_tile;
         // arrival counters of lockstep_arrive: when the grid fits the chip at once (it is sized to) and blocks share streams
-        const bool lockstep = !stream && (S & 7) == 0 && grid <= (big ? 256 : (small ? 1024 : 512)) && !getenv("HVS_NO_LOCKSTEP");
+        const bool lockstep = !stream && (S & 7) == 0 && grid <= slots && !getenv("HVS_NO_LOCKSTEP");
         const size_t ls_bytes = lockstep ? (size_t)8 * S * 4 : 0;
+        // the blocks pool what their first tile shows (exchange_bound): 16-bit operands, streams so short that a block's own
+        // bound gets nowhere (the condition a pass over a sample is taken under, which this replaces), every block resident
+        // and with a tile of its own, and at least 2 k published values per query
+        const int xm = S * wn_of_tile;
+        const bool xchg = want_xchg && tau0 == nullptr && (pp.dbg & ~512) == 0 && xchg_fits(S);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t xc_bytes = 0;
+        const size_t xv_bytes = xchg ? up((size_t)nq * xm * 4) + up((size_t)nq * 4) : 0;
+        const size_t pc_bytes = xchg ? up((size_t)nq * 4) : 0;  // pooled-list counters, zeroed with the arrival counters
+        const size_t keys_b = up((size_t)nq * P2 * k * 8);
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
-        HVS_TRY(hvs_ws_get(idx, 2, (size_t)nq * P2 * k * 8 + 512 + ls_bytes, &bufB));
+        HVS_TRY(hvs_ws_get(idx, 2, keys_b + up(64 + ls_bytes) + xc_bytes + pc_bytes + xv_bytes, &bufB));
         void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
-        int *overflow = (int *)((char *)bufB + (((size_t)nq * P2 * k * 8 + 15) & ~(size_t)15));
-        HVS_HIP(hipMemsetAsync(overflow, 0, 64 + ls_bytes, idx->stream));
+        int *overflow = (int *)((char *)bufB + keys_b);
+        char *xc = (char *)overflow + up(64 + ls_bytes);
+        HVS_HIP(hipMemsetAsync(overflow, 0, up(64 + ls_bytes) + xc_bytes + pc_bytes, idx->stream));
+        if (xchg) HVS_HIP(hipMemsetAsync(xc + xc_bytes + pc_bytes, 0xFF, xv_bytes, idx->stream));
         pp.prof = (unsigned long long *)(overflow + 4);
         pp.lockstep = lockstep ? (unsigned int *)(overflow + 16) : nullptr;
+        pp.pooled_count = xchg ? (unsigned int *)(xc + xc_bytes) : nullptr;
+        pp.xchg_min = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes) : nullptr;
+        pp.xchg_tau = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes + up((size_t)nq * xm * 4)) : nullptr;
         pp.cand = (uint64_t *)cand;
         pp.partial = (uint64_t *)bufA;
         pp.overflow = overflow;
@@ -1186,7 +1483,14 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
             else HVS_TRY(launch_stream_bm<HVS_BF16>(bm, false, pf, grid, idx->stream, pp));
         } else if (kdt == HVS_F32 && big) HVS_TRY((launch_search<HVS_F32, Tile256>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F32) HVS_TRY((launch_search<HVS_F32, Tile128>(pf, grid, idx->stream, pp)));
-        else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, pp)));
+        else if (xchg) {
+            if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64, true>(pf, grid, idx->stream, pp)));
+            else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128, true>(pf, grid, idx->stream, pp)));
+            else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256, true>(pf, grid, idx->stream, pp)));
+            else if (small) HVS_TRY((launch_search<HVS_BF16, Tile64, true>(pf, grid, idx->stream, pp)));
+            else if (!big) HVS_TRY((launch_search<HVS_BF16, Tile128, true>(pf, grid, idx->stream, pp)));
+            else HVS_TRY((launch_search<HVS_BF16, Tile256, true>(pf, grid, idx->stream, pp)));
+        } else if (kdt == HVS_F16 && small) HVS_TRY((launch_search<HVS_F16, Tile64>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F16 && !big) HVS_TRY((launch_search<HVS_F16, Tile128>(pf, grid, idx->stream, pp)));
         else if (kdt == HVS_F16) HVS_TRY((launch_search<HVS_F16, Tile256>(pf, grid, idx->stream, pp)));
         else if (small) HVS_TRY((launch_search<HVS_BF16, Tile64>(pf, grid, idx->stream, pp)));
@@ -1194,17 +1498,26 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, pp)));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
         HVS_TRY(hvs_prof_begin(idx));
-        HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, o_dist, o_ids, o_count, hi_only));
+        if (xchg) {
+            const int64_t *id_map = (hi_only || idx->emit_positions) ? nullptr : idx->ids;
+            const size_t slots_q = (size_t)S * k;
+            if (k <= 64) select_pooled_kernel<1><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            else if (k <= 128) select_pooled_kernel<2><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            else select_pooled_kernel<MFMA_MAX_K / 64><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            HVS_HIP(hipGetLastError());
+        } else
+            HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, o_dist, o_ids, o_count, hi_only));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
         int h_overflow = 0;
         HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));
         if (pp.dbg & 512) {
-            unsigned long long h_prof[4] = {0, 0, 0, 0};
+            unsigned long long h_prof[6] = {0, 0, 0, 0, 0, 0};
             HVS_HIP(hipMemcpy(h_prof, pp.prof, sizeof(h_prof), hipMemcpyDeviceToHost));
             const double waves = (double)grid * (big ? Tile256::NW : (small ? Tile64::NW : Tile128::NW));
-            fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f\n",
-                    h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves);
+            fprintf(stderr, "hvs prof (clock64 ticks per wave): k-loop+wait %.0f  epilogue %.0f  tile-end barrier %.0f  compaction %.0f  "
+                            "first-tile exchange %.0f  publishing %.0f\n",
+                    h_prof[0] / waves, h_prof[1] / waves, h_prof[2] / waves, h_prof[3] / waves, h_prof[4] / waves, h_prof[5] / waves);
         }
         HVS_REQUIRE(h_overflow == 0, "hvs_search: internal candidate array overflow (results would be incomplete)");
         return 0;
@@ -1219,7 +1532,13 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const int64_t n_rows = row_end - row_begin;
     const int slots_main = stream ? 256 : (big ? 256 : (small ? 1024 : 512));
     const int64_t rows_per_block = n_rows / ((slots_main + p.QT - 1) / p.QT);
-    bool prepass = (int64_t)k * 8192 > rows_per_block && n_rows >= 262144 && (!stream || k >= 64);
+    // short streams: the two-stage kernels on 16-bit operands pool their first tiles inside the launch (exchange_bound) where
+    // that applies; the pass over a sample stays for the ring kernel and for launches that cannot pool
+    const bool short_streams = (int64_t)k * 8192 > rows_per_block;
+    want_xchg = short_streams && !getenv("HVS_NO_XCHG");
+    if (const char *e = getenv("HVS_XCHG")) want_xchg = atoi(e) != 0;
+    const bool can_xchg = want_xchg && (p.dbg & ~512) == 0 && xchg_fits(splits_of((n_rows + bn - 1) / bn));
+    bool prepass = short_streams && n_rows >= 262144 && (!stream || k >= 64) && !can_xchg;
     if (const char *e = getenv("HVS_PREPASS")) prepass = atoi(e) != 0 && n_rows >= 4 * bn;
     const float *tau0 = nullptr;
     if (prepass) {
