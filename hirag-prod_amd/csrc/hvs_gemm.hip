@@ -55,7 +55,9 @@ struct SearchParams {
                       // and the K loop runs 3 split_steps steps: hi.hi, hi.lo, lo.hi (see hvs_split.hip)
     unsigned int *lockstep;  // optional: one arrival counter per (XCD, corpus split) -- see lockstep_arrive; zeroed before the launch
     // optional (kernels built with XCHG): the blocks of a query tile pool what their first corpus tile shows -- see exchange_bound
-    uint32_t *xchg_min;       // [nq_out][S * WN] ordered images of the smallest distance per (block, wave column); all ones before the launch
+    uint32_t *xchg_min;       // [S * xchg_w][nq_out] ordered images of the smallest distance per (block, wave column); all ones before the launch
+    int xchg_w;               // values a block publishes per query: one per wave column of its tile (T::WN), or 1 (their minimum)
+                              // where S * WN would pass the 1024 values one wave ranks
     uint32_t *xchg_tau;       // [nq_out] float bits of the bound derived from them; all ones (a NaN) before the launch
     unsigned int *pooled_count;  // optional (kernels built with XCHG): [nq_out] keys in a query's pooled list, zeroed before the launch;
                                  // `partial` then holds one list of S * k slots per query that every block appends its survivors to
@@ -492,7 +494,8 @@ __device__ __forceinline__ void exchange_bound(const SearchParams &p, const Bloc
                                                int lane, int wave, int tid) {
     constexpr int MT = T::MT, NT = T::NT, BMQ = T::BM / FOLD;
     const int h = lane >> 5;
-    const int M = p.S * T::WN;
+    const int W = p.xchg_w;  // T::WN or 1
+    const int M = p.S * W;
     const int64_t q0 = a_row0 / FOLD;
     __syncthreads();  // every wave is done with the fragments of the stage that now serves as scratch
     // 1. smallest distance per query over this wave's rows of the tile -> scratch[wn][query of the tile].  The distance
@@ -528,11 +531,13 @@ __device__ __forceinline__ void exchange_bound(const SearchParams &p, const Bloc
     }
     __syncthreads();
     // the block's WN x BMQ values, consecutive queries in consecutive lanes: xchg_min[(s * WN + wn)][query]
-    for (int i = tid; i < T::WN * BMQ; i += T::GT) {
+    for (int i = tid; i < W * BMQ; i += T::GT) {
         const int w = i / BMQ, ql = i - w * BMQ;
+        float m = scratch[i];
+        if (W == 1)
+            for (int o = 1; o < T::WN; o++) m = fminf(m, scratch[o * BMQ + ql]);
         if (q0 + ql < p.nq_out)
-            __hip_atomic_store(p.xchg_min + (size_t)(s * T::WN + w) * p.nq_out + q0 + ql, hvs_ord(scratch[i]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.xchg_min + (size_t)(s * W + w) * p.nq_out + q0 + ql, hvs_ord(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // 2. this block's share of the tile's queries: the k-th smallest of the M published values, as soon as they are there
     for (int ql = s + wave * p.S; ql < BMQ; ql += T::NW * p.S) {
@@ -1391,6 +1396,17 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const int stream_max = 128;
     bool stream = kdt != HVS_F32 && nA <= stream_max && row_end - row_begin >= 256 * 256;
     if (const char *e = getenv("HVS_STREAM")) stream = kdt != HVS_F32 && nA <= stream_max && atoi(e) != 0;  // 1 forces it at any size, 0 disables it
+    else if (stream && !getenv("HVS_NO_XCHG")) {
+        // ... unless the stream is short: below about 4 GB of rows the two-stage kernel, whose blocks pool their first tiles
+        // (exchange_bound), is as fast or faster at every batch size (195 k x 768 bf16, k = 100: 8 / 64 / 128 queries 0.077 /
+        // 0.096 / 0.108 ms against 0.073 / 0.194 / 0.320 ms on the ring; 3.1M rows: 0.83 / 1.06 / 1.22 against 0.80 / 0.98 /
+        // 1.27; on 12.5M rows the ring leads by 5 - 10 % up to 64 queries)
+        const bool sm = nA <= 32;
+        const int64_t rows = row_end - row_begin, t2 = (rows + (sm ? 64 : 128) - 1) / (sm ? 64 : 128);
+        const int64_t s2 = t2 < (sm ? 1024 : 512) ? (t2 >= 8 ? t2 / 8 * 8 : t2) : (sm ? 1024 : 512);
+        const bool fits = s2 * 2 >= 2 * k && (s2 * 2 <= 1024 || s2 >= 2 * k);
+        if (fits && (int64_t)k * 8192 > rows / s2 && (double)rows * ld_bytes < 4.0e9) stream = false;
+    }
     // tile shape of the two-stage kernel: 16-bit rows with more than one 128-row tile of queries take the 256 x 256 block tile
     bool big = kdt != HVS_F32 && nA > Tile128::BM;
     if (const char *e = getenv("HVS_TILE")) big = kdt != HVS_F32 && atoi(e) == 256;
@@ -1433,7 +1449,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // can the blocks of such a launch pool their first tiles (exchange_bound)?  16-bit operands on the two-stage kernel,
     // every block resident at once, at most 1024 and at least 2 k published values per query
     auto xchg_fits = [&](int S) -> bool {
-        return !stream && kdt != HVS_F32 && p.QT * S <= slots_of_tile && S * wn_of_tile <= 1024 && S * wn_of_tile >= 2 * k;
+        return !stream && kdt != HVS_F32 && p.QT * S <= slots_of_tile && S <= 1024 && S * wn_of_tile >= 2 * k &&
+               (S * wn_of_tile <= 1024 || S >= 2 * k);
     };
     // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
     auto run_pass = [&](SearchParams pp, int64_t rb, int64_t re, const float *tau0, float *o_dist, int64_t *o_ids, int32_t *o_count) -> int {
@@ -1455,7 +1472,9 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         // the blocks pool what their first tile shows (exchange_bound): 16-bit operands, streams so short that a block's own
         // bound gets nowhere (the condition a pass over a sample is taken under, which this replaces), every block resident
         // and with a tile of its own, and at least 2 k published values per query
-        const int xm = S * wn_of_tile;
+        const int xw = S * wn_of_tile <= 1024 ? wn_of_tile : 1;
+        const int xm = S * xw;
+        pp.xchg_w = xw;
         const bool xchg = want_xchg && tau0 == nullptr && (pp.dbg & ~512) == 0 && xchg_fits(S);
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t xc_bytes = 0;
