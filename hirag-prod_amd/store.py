@@ -182,6 +182,41 @@ class _Table:
         # epoch moved between its launch and its metadata look-up is run again (PostgreSQL gives the reference snapshot
         # isolation for the same situation)
         self.epoch = 0
+        # Row positions on the device differ from the positions in `rows` once the table has been put in group order
+        # (HvsIndex.partition): d2h[device position] = position here, h2d the inverse, both None while they are equal.
+        # The index's ids are positions HERE, so what a search returns needs no translation; what goes to the index
+        # by position (gather, tombstones, a host-built row mask, a distance column) goes through these.  Rows appended
+        # after a partition sit at the same position on both sides (the maps cover the rows of the last partition).
+        self.d2h: Optional[np.ndarray] = None
+        self.h2d: Optional[np.ndarray] = None
+        self.part_rows = 0       # rows the last partition put in group order
+        self.part_failed_n = 0   # row count at which a partition last failed (device memory): not tried again below twice that
+
+    def to_device(self, positions) -> np.ndarray:
+        """positions in ``rows`` -> row positions of the index"""
+        pos = np.asarray(positions, dtype=np.int64)
+        if self.h2d is None or pos.size == 0:
+            return pos
+        out = pos.copy()
+        inside = pos < len(self.h2d)
+        out[inside] = self.h2d[pos[inside]]
+        return out
+
+    def host_order(self, column: np.ndarray) -> np.ndarray:
+        """a per-row array in the index's row order -> the same in the order of ``rows``"""
+        if self.h2d is None:
+            return column
+        out = column.copy()
+        out[: len(self.h2d)] = column[self.h2d]
+        return out
+
+    def device_order(self, column: np.ndarray) -> np.ndarray:
+        """a per-row array in the order of ``rows`` -> the same in the index's row order"""
+        if self.d2h is None:
+            return column
+        out = column.copy()
+        out[: len(self.d2h)] = column[self.d2h]
+        return out
 
     # -- secondary indexes on scalar columns (documentKey, uri, ...): value -> ascending row positions.
     # Built on first use, kept current by note_insert / note_delete, dropped when positions change.
@@ -311,11 +346,19 @@ class HipVectorStore(BaseVDB):
         graph_factory: Optional[Callable[..., Any]] = None,
         coalesce_queries: bool = True,
         search_copy: bool = True,
+        auto_partition: bool = True,
+        partition_min_rows: int = 32768,
     ):
         """``search_copy``: a ``vector`` (fp32) table serves batched searches, single queries on large tables and
         k-means from a second, fp16-slab copy of its rows on the 16-bit matrix pipe -- several times faster, and as
         much device memory again as the rows.  False keeps every table at its own size (fp32 kernels only).  The
         store logs one line per table when such a copy appears.
+
+        ``auto_partition``: every ``query`` of the reference filters by (workspaceId, knowledgeBaseId)
+        (``pgvector.py:577-580``); a table kept in the order of that pair answers the filter with a row range
+        (``partition``).  With this set, a table is put in that order when the rows added since the last time are at
+        least ``partition_min_rows`` and at least as many as the ordered rows (so the copying stays proportional to the
+        table's growth); ``prepare`` does it whatever the size.
 
         ``vector_type`` None: the environment decides, as it does for the reference's column type
         (``USE_HALF_VEC``, true unless set otherwise -> ``halfvec``; ``schema/vector_config.py:8-11``).
@@ -345,6 +388,8 @@ class HipVectorStore(BaseVDB):
         self._coalescer = _SearchCoalescer(self._search_batch) if coalesce_queries else None
         self.search_copy = bool(search_copy)
         self._copy_logged: Dict[str, int] = {}
+        self.auto_partition = bool(auto_partition)
+        self.partition_min_rows = int(partition_min_rows)
 
     # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
     @classmethod
@@ -539,6 +584,14 @@ class HipVectorStore(BaseVDB):
                     table.rows.append(stored)
                     table.pk_map[pk] = first + j
                     table.note_insert(first + j, stored)
+                tail = len(table.rows) - table.part_rows
+                if (self.auto_partition and len(self._group_codes) > 1 and tail >= max(self.partition_min_rows, table.part_rows)
+                        and len(table.rows) >= 2 * table.part_failed_n and hasattr(index, "partition")):
+                    try:
+                        await self._partition_table(table)
+                    except Exception as exc:  # noqa: BLE001 -- the rows are in; the table merely stays in arrival order
+                        table.part_failed_n = len(table.rows)
+                        logger.warning("[partition] table '%s' stays in arrival order: %s", table_name, exc)
 
     @staticmethod
     def _add_rows(index, mat, groups, attrs):
@@ -599,7 +652,7 @@ class HipVectorStore(BaseVDB):
                 # tombstones on the device first: from then on no search returns these positions, and a search already
                 # under way that does finds the host rows gone and skips them
                 if table.index is not None:
-                    await asyncio.to_thread(table.index.set_deleted, np.asarray(hit, dtype=np.int64), True)
+                    await asyncio.to_thread(table.index.set_deleted, table.to_device(hit), True)
                 for pos in hit:
                     row = table.rows[pos]
                     table.pk_map.pop(tuple(row.get(c) for c in table.pk), None)
@@ -702,7 +755,7 @@ class HipVectorStore(BaseVDB):
                     pairs = await asyncio.to_thread(self._search, table, q, int(topk), spec, float(distance_threshold))
                 vecs = None
                 if want_vec and pairs:
-                    vecs = await asyncio.to_thread(table.index.gather, np.asarray([p for p, _ in pairs], dtype=np.int64))
+                    vecs = await asyncio.to_thread(table.index.gather, table.to_device([p for p, _ in pairs]))
                 if table.epoch != epoch:
                     continue  # positions were renumbered under this search: its answer names other rows now
                 for j, (pos, dist) in enumerate(pairs):
@@ -742,7 +795,7 @@ class HipVectorStore(BaseVDB):
             keep &= table.kb_code[:n] == kb
         if access is not None:
             keep &= table.private[:n] == access
-        bits = np.packbits(keep, bitorder="little")
+        bits = np.packbits(table.device_order(keep), bitorder="little")  # the index tests bit (its own row position)
         pad = (-len(bits)) % 4
         if pad:
             bits = np.concatenate([bits, np.zeros(pad, dtype=np.uint8)])
@@ -827,7 +880,7 @@ class HipVectorStore(BaseVDB):
                 break
         vecs = None
         if "vector" in columns_to_select and table.has_vector and hits and table.index is not None:
-            vecs = await asyncio.to_thread(table.index.gather, np.asarray(hits, dtype=np.int64))
+            vecs = await asyncio.to_thread(table.index.gather, table.to_device(hits))
         out: List[dict] = []
         for j, pos in enumerate(hits):
             row = table.rows[pos]
@@ -887,12 +940,12 @@ class HipVectorStore(BaseVDB):
                         for s in range(0, q.shape[0], _MAX_DIST_FOLD):
                             part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_DIST_FOLD])
                             col = part if col is None else np.fmin(col, part)  # fmin: NaN only if both are NaN
-                    computed[name] = col
+                    computed[name] = None if col is None else table.host_order(col)
             if table.epoch == epoch:
                 break
         vecs = None
         if "vector" in columns_to_select and table.has_vector and hits and table.index is not None:
-            vecs = await asyncio.to_thread(table.index.gather, np.asarray(hits, dtype=np.int64))
+            vecs = await asyncio.to_thread(table.index.gather, table.to_device(hits))
         out: List[dict] = []
         for j, pos in enumerate(hits):
             row = table.rows[pos]
@@ -944,7 +997,7 @@ class HipVectorStore(BaseVDB):
         live = [pos for pos, row in enumerate(table.rows) if row is not None]
         vecs = None
         if table.has_vector and table.index is not None and live:
-            vecs = await asyncio.to_thread(table.index.gather, np.asarray(live, dtype=np.int64))
+            vecs = await asyncio.to_thread(table.index.gather, table.to_device(live))
         out = []
         for j, pos in enumerate(live):
             rec = {col: table.rows[pos].get(col) for col in table.columns if col != "vector"}
@@ -1001,6 +1054,7 @@ class HipVectorStore(BaseVDB):
         for s in range(0, q.shape[0], _MAX_DIST_FOLD):
             part = await asyncio.to_thread(table.index.distances, q[s : s + _MAX_DIST_FOLD])
             col = part if col is None else np.fmin(col, part)  # fmin: NaN only if both are NaN
+        col = table.host_order(col)
         out = []
         for pos, row in enumerate(table.rows):
             if row is None:
@@ -1022,6 +1076,11 @@ class HipVectorStore(BaseVDB):
         out: Dict[str, bool] = {}
         for name in ([table_name] if table_name else list(self.tables)):
             table = self.get_model(name)
+            if table.index is not None and len(table.rows) and hasattr(table.index, "partition"):
+                try:
+                    await self.partition(name)
+                except Exception as exc:  # noqa: BLE001 -- not enough device memory to move the rows: searches keep the per-row test
+                    logger.warning("[partition] table '%s' stays in arrival order: %s", name, exc)
             if table.index is not None and hasattr(table.index, "prepare"):
                 out[name] = bool(await asyncio.to_thread(table.index.prepare))
                 self._note_search_copy(table)
@@ -1030,7 +1089,8 @@ class HipVectorStore(BaseVDB):
     # -- compaction and snapshots (the table outlives deletes and restarts) --------------------------
     async def compact(self, table_name: Optional[str] = None) -> Dict[str, int]:
         """Reclaim the rows ``clean_table`` deleted: tombstoned rows leave HBM and the host lists, the
-        survivors keep their order.  Returns ``{table: live rows}`` for the tables compacted."""
+        survivors keep their order (a table in group order is put in that order again, which drops them as well).
+        Returns ``{table: live rows}`` for the tables compacted."""
         names = [table_name] if table_name else list(self.tables)
         out: Dict[str, int] = {}
         async with self._lock:
@@ -1039,21 +1099,78 @@ class HipVectorStore(BaseVDB):
                 n = len(table.rows)
                 keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
                 if len(keep) != n:
-                    table.epoch += 1  # odd: searches launched from here on wait, those under way will notice and run again
-                    try:
-                        if table.index is not None:
-                            left = await asyncio.to_thread(table.index.compact, True)
-                            if left != len(keep):
-                                raise RuntimeError(f"table {name}: {left} rows left on the device, {len(keep)} on the host")
-                        table.rows = table.rows.take(keep.tolist())
-                        for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
-                            setattr(table, col, getattr(table, col)[:n][keep].copy())
-                        table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
-                        table.key_index.clear()
-                    finally:
-                        table.epoch += 1
+                    if table.index is not None and (table.d2h is not None or table.part_rows):
+                        await self._partition_table(table)
+                    else:
+                        table.epoch += 1  # odd: searches launched from here on wait, those under way will notice and run again
+                        try:
+                            if table.index is not None:
+                                left = await asyncio.to_thread(table.index.compact, True)
+                                if left != len(keep):
+                                    raise RuntimeError(f"table {name}: {left} rows left on the device, {len(keep)} on the host")
+                            self._compact_host_rows(table, keep)
+                        finally:
+                            table.epoch += 1
                 out[name] = len(table.rows)
         return out
+
+    @staticmethod
+    def _compact_host_rows(table: _Table, keep: np.ndarray) -> None:
+        n = len(table.rows)
+        table.rows = table.rows.take(keep.tolist())
+        for col in ("group", "ws_code", "kb_code", "uri_code", "private", "live"):
+            setattr(table, col, getattr(table, col)[:n][keep].copy())
+        table.pk_map = {tuple(row.get(c) for c in table.pk): pos for pos, row in enumerate(table.rows)}
+        table.key_index.clear()
+
+    async def partition(self, table_name: Optional[str] = None) -> Dict[str, int]:
+        """Put the embedded tables (or one) in the order of their (workspaceId, knowledgeBaseId) pairs on the device, so
+        that the WHERE on that pair, which every ``query`` carries (``pgvector.py:577-580``), selects a row range:
+        no per-row test, no per-query compaction.  Deleted rows are dropped on the way (as ``compact`` does).  Rows
+        added afterwards are found by the old per-row test until the next call; the store calls this by itself as a
+        table grows (``auto_partition``).  Needs as much free device memory as the table holds.  Returns
+        ``{table: rows in group order}``."""
+        out: Dict[str, int] = {}
+        async with self._lock:
+            for name in ([table_name] if table_name else list(self.tables)):
+                table = self.get_model(name)
+                if table.index is not None and table.has_vector and hasattr(table.index, "partition"):
+                    await self._partition_table(table)
+                    out[name] = table.part_rows
+        return out
+
+    async def _partition_table(self, table: _Table) -> None:
+        """(store lock held)  The index's ids are positions in ``table.rows`` and travel with the rows, so searches under
+        way stay valid unless deleted rows leave the host lists too, which renumbers them: only then does the epoch move."""
+        index = table.index
+        n = len(table.rows)
+        keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
+        renumber = len(keep) != n
+        if renumber:
+            table.epoch += 1
+        try:
+            await asyncio.to_thread(index.partition, False)
+            ids = np.asarray(await asyncio.to_thread(index.ids), dtype=np.int64)  # device position -> position in table.rows
+            if len(ids) != len(keep):
+                raise RuntimeError(f"table {table.name}: {len(ids)} rows left on the device, {len(keep)} on the host")
+            if renumber:
+                rank = np.full(n, -1, dtype=np.int64)
+                rank[keep] = np.arange(len(keep), dtype=np.int64)
+                ids = rank[ids]
+                if ids.min(initial=0) < 0:
+                    raise RuntimeError(f"table {table.name}: the device kept a row the host has deleted")
+                await asyncio.to_thread(index.set_ids, 0, ids)
+                self._compact_host_rows(table, keep)
+            if np.array_equal(ids, np.arange(len(ids), dtype=np.int64)):
+                table.d2h = table.h2d = None
+            else:
+                table.d2h = ids
+                table.h2d = np.empty(len(ids), dtype=np.int64)
+                table.h2d[ids] = np.arange(len(ids), dtype=np.int64)
+            table.part_rows = int(index.partition_info()[0]) if hasattr(index, "partition_info") else len(ids)
+        finally:
+            if renumber:
+                table.epoch += 1
 
     @staticmethod
     def _json_default(v):
@@ -1094,7 +1211,8 @@ class HipVectorStore(BaseVDB):
             meta = {"format": 1, "vector_type": self.vector_type, "embedding_dimension": self.embedding_dimension,
                     "workspaces": keys_by_code(self._ws_codes), "knowledge_bases": keys_by_code(self._kb_codes),
                     "uris": keys_by_code(self._uri_codes), "groups": keys_by_code(self._group_codes),
-                    "tables": {name: {"rows": len(t.rows), "indexed": t.index is not None} for name, t in self.tables.items()}}
+                    "tables": {name: {"rows": len(t.rows), "indexed": t.index is not None, "partitioned": bool(t.part_rows)}
+                               for name, t in self.tables.items()}}
             for name, table in self.tables.items():
                 with open(os.path.join(directory, f"{name}.rows.jsonl"), "w") as fh:
                     for row in table.rows:
@@ -1150,9 +1268,22 @@ class HipVectorStore(BaseVDB):
                     read_index, os.path.join(directory, f"{name}.hvs"), lambda dim, dtype: store._make_index(dim))
                 if len(table.index) != n or table.index.dtype != store.dtype:
                     raise ValueError(f"{directory}: {name}.hvs does not match the store ({len(table.index)} rows, {table.index.dtype})")
-                if n:  # the attribute columns are rebuilt from the metadata rows
-                    await asyncio.to_thread(table.index.set_attributes, 0, table.ws_code[:n], table.kb_code[:n], table.uri_code[:n],
-                                            table.private[:n])
+                if n:
+                    # the snapshot holds the rows in the index's order and their ids, which are positions in the metadata rows
+                    ids = np.asarray(await asyncio.to_thread(table.index.ids), dtype=np.int64) if hasattr(table.index, "ids") else np.arange(n)
+                    if not np.array_equal(ids, np.arange(n, dtype=np.int64)):
+                        if not np.array_equal(np.sort(ids), np.arange(n, dtype=np.int64)):
+                            raise ValueError(f"{directory}: the ids of {name}.hvs are not the positions of {name}.rows.jsonl")
+                        table.d2h = ids
+                        table.h2d = np.empty(n, dtype=np.int64)
+                        table.h2d[ids] = np.arange(n, dtype=np.int64)
+                    # the attribute columns are rebuilt from the metadata rows
+                    await asyncio.to_thread(table.index.set_attributes, 0, table.device_order(table.ws_code[:n]),
+                                            table.device_order(table.kb_code[:n]), table.device_order(table.uri_code[:n]),
+                                            table.device_order(table.private[:n]))
+        for name, info in meta["tables"].items():
+            if info.get("partitioned") and store.tables[name].index is not None:
+                await store.partition(name)  # the row ranges are not part of a snapshot; rows already in order do not move
         return store
 
     # -- graph side ----------------------------------------------------------------------------------

@@ -31,7 +31,9 @@ class OracleIndex:
         self.rows = np.zeros((0, dim), dtype=np.float32)
         self.groups = np.zeros(0, dtype=np.int32)
         self.deleted = np.zeros(0, dtype=bool)
-        self.attrs = np.zeros((0, 4), dtype=np.int32)  # workspace, knowledge base, uri, private
+        self.attrs = np.zeros((0, 4), dtype=np.int32)  # workspace, knowledge base, uri, private (-1: not set yet, matches no clause)
+        self.ids_arr = np.zeros(0, dtype=np.int64)  # external ids (position at insertion unless given)
+        self.part_n = 0  # rows at the front that are in group order
         self.fail_next_add = None  # an exception the next add() raises (what a failed hipMalloc looks like to the store)
 
     def __len__(self):
@@ -51,7 +53,9 @@ class OracleIndex:
         g = np.zeros(rows.shape[0], np.int32) if group_codes is None else np.asarray(group_codes, np.int32)
         self.groups = np.concatenate([self.groups, g])
         self.deleted = np.concatenate([self.deleted, np.zeros(rows.shape[0], bool)])
-        self.attrs = np.concatenate([self.attrs, np.zeros((rows.shape[0], 4), np.int32)])
+        self.attrs = np.concatenate([self.attrs, np.full((rows.shape[0], 4), -1, np.int32)])
+        new_ids = np.arange(first, first + rows.shape[0], dtype=np.int64) if ids is None else np.asarray(ids, np.int64)
+        self.ids_arr = np.concatenate([self.ids_arr, new_ids])
         return first, len(self)
 
     @_serialised
@@ -75,7 +79,7 @@ class OracleIndex:
             if filter.get("uris") is not None:
                 keep &= np.isin(self.attrs[:, 2], np.asarray(list(filter["uris"]), dtype=np.int32))
             if filter.get("access") is not None:
-                keep &= (self.attrs[:, 3] != 0) == bool(filter["access"])
+                keep &= (self.attrs[:, 3] >= 0) & ((self.attrs[:, 3] != 0) == bool(filter["access"]))
         if group_filter >= 0:
             keep &= self.groups == group_filter
         if row_mask is not None:
@@ -96,7 +100,7 @@ class OracleIndex:
                               threshold=None if math.isinf(max_distance) else max_distance, keep=keep,
                               storage=self.dtype)
             cnt[i] = len(idx)
-            ids[i, : len(idx)] = idx
+            ids[i, : len(idx)] = self.ids_arr[idx]
             dist[i, : len(idx)] = d
         return dist, ids, cnt
 
@@ -116,11 +120,11 @@ class OracleIndex:
         n = len(self)
         hit[:row_begin] = False
         hit[n if row_end < 0 else row_end :] = False
-        ids = np.flatnonzero(hit).astype(np.int64)
-        total = len(ids)
+        pos = np.flatnonzero(hit).astype(np.int64)
+        total = len(pos)
         if capacity is not None:
-            ids = ids[:capacity]
-        return d[ids], ids, total
+            pos = pos[:capacity]
+        return d[pos], self.ids_arr[pos], total
 
     @_serialised
     def gather(self, positions):
@@ -132,9 +136,33 @@ class OracleIndex:
     @_serialised
     def compact(self, renumber_ids=False):
         keep = ~self.deleted
+        self.part_n = int(keep[: self.part_n].sum())
         self.rows, self.groups, self.deleted = self.rows[keep], self.groups[keep], np.zeros(int(keep.sum()), bool)
         self.attrs = self.attrs[keep]
+        self.ids_arr = np.arange(len(self), dtype=np.int64) if renumber_ids else self.ids_arr[keep]
         return len(self)
+
+    @_serialised
+    def partition(self, renumber_ids=False):
+        live = np.flatnonzero(~self.deleted)
+        order = live[np.argsort(self.groups[live], kind="stable")]
+        self.rows, self.groups, self.attrs = self.rows[order], self.groups[order], self.attrs[order]
+        self.deleted = np.zeros(len(order), bool)
+        self.ids_arr = np.arange(len(order), dtype=np.int64) if renumber_ids else self.ids_arr[order]
+        self.part_n = len(order)
+        return order.astype(np.int64)
+
+    def partition_info(self):
+        return self.part_n, len(np.unique(self.groups[: self.part_n]))
+
+    @_serialised
+    def set_ids(self, first, ids):
+        ids = np.asarray(ids, np.int64)
+        self.ids_arr[first : first + len(ids)] = ids
+
+    def ids(self, first=0, n=None):
+        n = len(self) - first if n is None else n
+        return self.ids_arr[first : first + n].copy()
 
     @_serialised
     def export(self, first=0, n=None):
@@ -147,7 +175,7 @@ class OracleIndex:
             stored = stored.astype(np.float16)
         else:
             stored = stored.astype(np.float32)
-        return stored, np.arange(first, first + n, dtype=np.int64), self.groups[sl].copy(), self.deleted[sl].copy()
+        return stored, self.ids_arr[sl].copy(), self.groups[sl].copy(), self.deleted[sl].copy()
 
     def close(self):
         pass

@@ -469,6 +469,106 @@ async def scenario_compact_and_snapshot(store, load_store, storage, directory):
     again.close()
 
 
+async def scenario_partition(store, load_store, storage, directory):
+    """A table put in the order of its (workspaceId, knowledgeBaseId) pairs answers like the table in arrival order:
+    queries with every kind of filter, vectors by key, distance columns, deletes, appends behind the ordered rows (by
+    hand and by the store's own rule), compaction, snapshots."""
+    from hirag_prod_amd import select_expr
+
+    await store._init_vdb(embedding_dimension=DIM)
+    store.auto_partition = False
+    spaces = [("ws1", "kb1"), ("ws2", "kb1"), ("ws1", "kb2"), ("ws3", "kb1")]
+    props = [chunk_props(i, ws=spaces[i % 4][0], kb=spaces[(i * 7) % 4 if i % 5 == 0 else i % 4][1], private=(i % 6 == 0)) for i in range(240)]
+    texts = [p["text"] for p in props]
+    await store.upsert_texts(texts[:160], props[:160], "Chunks")
+    items = [dict(chunk_props(i, ws=spaces[i % 4][0], kb=spaces[i % 4][1]), documentKey=f"item-{i}", chunkIdx=i, pageNumber=i % 7) for i in range(60)]
+    await store.upsert_texts([f"item text {i}" for i in range(60)], items, "Items")
+    known = 160
+
+    async def probe(s):
+        out = []
+        for ws, kb in spaces:
+            out.append(await s.query([f"text {ws} {kb} 12", f"text {ws} {kb} 40"], ws, kb, "Chunks", topk=12, distance_threshold=1.6,
+                                     columns_to_select=["documentKey", "chunkIdx"]))
+        out.append(await s.query("text ws1 kb1 8", "ws1", "kb1", "Chunks", topk=6, distance_threshold=1.9, require_access="public",
+                                 uri_list=["s3://bucket/file0.pdf", "s3://bucket/file2.pdf"]))
+        out.append(await s.query("text ws2 kb1 9", "ws2", "", "Chunks", topk=7, distance_threshold=1.9))
+        out.append(await s.query("text ws1 kb1 8", "ws1", "kb1", "Chunks", topk=3, topn=3, columns_to_select=["documentKey", "vector"], distance_threshold=1.9))
+        keys = [props[i]["documentKey"] for i in (0, 5, 44, 131) if i < known]
+        out.append(sorted(((r["documentKey"], r["vector"]) for r in await s.query_by_keys(keys, "", "", "Chunks", columns_to_select=["documentKey", "vector"])),
+                          key=lambda t: t[0]))
+        emb = np.stack([embed_text("item text 3"), embed_text("item text 30")])
+        out.append(sorted(((r["documentKey"], r["search_sentence_cosine_distance"]) for r in
+                           await s.query_distance_column(emb, "ws1", "kb1", "Items", columns_to_select=["documentKey"])), key=lambda t: t[0]))
+        out.append(sorted(((r["documentKey"], r["search_sentence_cosine_distance"]) for r in
+                           await s.query_distance_column(emb, "ws2", "kb1", "Items", columns_to_select=["documentKey"], max_distance=0.95)),
+                          key=lambda t: t[0]))
+        rows = await s.query_by_keys([], "ws1", "kb1", "Items", key_column="documentKey", columns_to_select=["documentKey"],
+                                     additional_data_to_select={"d": select_expr.LeastCosineDistance(emb)}, order_by=["chunkIdx"], limit=9)
+        out.append([(r["documentKey"], r["d"]) for r in rows])
+        out.append(sorted((r["documentKey"], tuple(r["vector"][:3])) for r in await s.get_table("Items")))
+        return out
+
+    def oracle_check(res, ws, kb, qs, k, thr, n_known, dead):
+        keep = np.array([p["workspaceId"] == ws and p["knowledgeBaseId"] == kb for p in props[:n_known]]) & ~dead[:n_known]
+        idx, dist = expected_hits(texts[:n_known], keep, qs, k, thr, storage)
+        same_hits([r["documentKey"] for r in res], [props[i]["documentKey"] for i in idx], dist, [r["distance"] for r in res])
+
+    dead = np.zeros(len(props), bool)
+    before = await probe(store)
+    oracle_check(before[0], "ws1", "kb1", ["text ws1 kb1 12", "text ws1 kb1 40"], 12, 1.6, known, dead)
+    done = await store.partition()
+    chunks = store.tables["Chunks"]
+    assert done["Chunks"] == 160 and chunks.part_rows == 160 and chunks.d2h is not None and chunks.epoch == 0
+    assert sorted(chunks.d2h.tolist()) == list(range(160)) and np.array_equal(chunks.h2d[chunks.d2h], np.arange(160))
+    assert await probe(store) == before  # same keys, same distances bit for bit, same vectors
+
+    # deletes: tombstones through the position map; then the partition drops them, which renumbers the host rows too
+    assert await store.clean_table("Chunks", {"uri": "s3://bucket/file1.pdf"}) is True
+    assert await store.clean_table("Items", {"pageNumber": 3}) is True
+    dead[:known] |= np.array([p["uri"].endswith("file1.pdf") for p in props[:known]])
+    with_tombstones = await probe(store)
+    oracle_check(with_tombstones[1], "ws2", "kb1", ["text ws2 kb1 12", "text ws2 kb1 40"], 12, 1.6, known, dead)
+    await store.partition("Chunks")
+    assert chunks.epoch == 2 and len(chunks.rows) == int((~dead[:known]).sum()) == len(chunks.index)
+    left = await store.compact("Items")  # a partitioned table is compacted by ordering it again
+    assert left["Items"] == len(store.tables["Items"].index) == sum(1 for it in items if it["pageNumber"] != 3)
+    assert await probe(store) == with_tombstones
+
+    # appends behind the ordered rows: found by the per-row test and merged with the group's range
+    await store.upsert_texts(texts[160:200], props[160:200], "Chunks")
+    known = 200
+    assert chunks.part_rows < len(chunks.rows)
+    with_tail = await probe(store)
+    for j, (ws, kb) in enumerate(spaces):
+        oracle_check(with_tail[j], ws, kb, [f"text {ws} {kb} 12", f"text {ws} {kb} 40"], 12, 1.6, known, dead)
+    # the store's own rule: once the rows added since are as many as the ordered ones (and past the minimum) it orders the table
+    store.auto_partition, store.partition_min_rows = True, 30
+    await store.upsert_texts(texts[200:240], props[200:240], "Chunks")
+    known = 240
+    assert len(chunks.rows) - chunks.part_rows == 80  # 80 behind 107 ordered rows: not yet
+    extra = [chunk_props(1000 + i, ws="ws4", kb="kb1") for i in range(40)]
+    await store.upsert_texts([p["text"] for p in extra], extra, "Chunks")
+    assert chunks.part_rows == len(chunks.rows) == len(chunks.index), "120 rows behind 107: the table is put in order"
+    store.auto_partition = False
+    full = await probe(store)
+    for j, (ws, kb) in enumerate(spaces):
+        oracle_check(full[j], ws, kb, [f"text {ws} {kb} 12", f"text {ws} {kb} 40"], 12, 1.6, known, dead)
+    res = await store.query(extra[7]["text"], "ws4", "kb1", "Chunks", topk=1, topn=1)
+    assert res[0]["documentKey"] == extra[7]["documentKey"] and res[0]["distance"] < 1e-3
+
+    # a snapshot keeps the order; the loaded store has its row ranges again
+    await store.upsert_texts(["late row"], [chunk_props(5000, ws="ws2", kb="kb1")], "Chunks")  # one row behind the ordered part
+    final = await probe(store)
+    await store.save(directory)
+    again = await load_store(directory)
+    assert again.tables["Chunks"].part_rows == len(again.tables["Chunks"].rows) == len(chunks.rows)
+    assert await probe(again) == final
+    res = await again.query("late row", "ws2", "kb1", "Chunks", topk=1, topn=1)
+    assert res[0]["chunkIdx"] == 5000 and res[0]["distance"] < 1e-3
+    again.close()
+
+
 async def scenario_concurrent_queries(store, storage):
     """Many ``query`` coroutines in flight at once (the reference's evaluation runs 25): they share launches, and
     every caller gets what it would have got alone -- different tables, workspaces, k, fold and thresholds mixed."""

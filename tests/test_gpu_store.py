@@ -165,3 +165,15 @@ def test_search_copy_knob_and_log_line(caplog):
     assert idx.search_copy(False) == 0 and not idx.prepare()
     assert idx.search_copy(True) == 0 and idx.prepare() and idx.search_copy() > 0
     idx.close()
+
+
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32"), ("bf16", "bf16")])
+def test_store_in_group_order_gpu(tmp_path, vector_type, storage):
+    import hirag_prod_amd.store as st
+
+    async def load(directory):
+        return await st.HipVectorStore.load(directory, store_cases.make_embedding_func())
+
+    s = _store(vector_type)
+    store_cases.run(store_cases.scenario_partition(s, load, storage, str(tmp_path / "snap")))
+    s.close()

@@ -59,6 +59,17 @@ def test_store_compact_and_snapshot(tmp_path, vector_type, storage):
     store_cases.run(store_cases.scenario_compact_and_snapshot(_store(vector_type), load, storage, str(tmp_path / "snap")))
 
 
+@pytest.mark.parametrize("vector_type,storage", [("halfvec", "f16"), ("vector", "f32")])
+def test_store_in_group_order(tmp_path, vector_type, storage):
+    import hirag_prod_amd.store as st
+
+    async def load(directory):
+        return await st.HipVectorStore.load(directory, store_cases.make_embedding_func(),
+                                            index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device))
+
+    store_cases.run(store_cases.scenario_partition(_store(vector_type), load, storage, str(tmp_path / "snap")))
+
+
 def test_store_is_a_basevdb_and_refuses_without_gpu():
     import hirag_prod_amd as hvs
     import hirag_prod_amd.store as st
