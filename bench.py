@@ -235,14 +235,24 @@ def leg_cfg4(idx, hvs, _lib, torch, dev, rows):
     return out
 
 
-def leg_cfg5(hvs, _lib, torch, dev):
-    """BASELINE config 5, one GPU's shard: 12.5M x 768 bf16 (1/8 of 100M), top-100, 64 workspaces."""
-    n, d, k = 12_500_000, 768, 100
+def leg_cfg5(hvs, _lib, torch, dev, n=12_500_000, first_global_row=25_000_000, what="shard (rank 2 of 8 of a 100M-row table)"):
+    """BASELINE config 5: 12.5M x 768 bf16 (one GPU's 1/8 of 100M rows) or the whole 100M-row table on one GPU; top-100,
+    64 workspaces.  The table is put in group order first (hvs_index_partition), as the store keeps its tables: the
+    workspace filter then selects a row range.  The whole table (154 GB) cannot be reordered on one GPU -- the rows move
+    through a second set of arrays -- and keeps the per-row test."""
+    d, k = 768, 100
     idx = hvs.HvsIndex(d, "bf16", device=dev.index)
-    idx.fill_synthetic(n, seed=SEED_CORPUS, first_global_row=25_000_000, n_groups=64)
+    idx.reserve(n)
+    idx.fill_synthetic(n, seed=SEED_CORPUS, first_global_row=first_global_row, n_groups=64)
     gen = torch.Generator(device=dev).manual_seed(SEED_QUERY)
     q = torch.randn((256, d), device=dev, dtype=torch.float32, generator=gen)
-    out = {"workload": f"{n} x {d} bf16 shard (rank 2 of 8 of a 100M-row table), top-{k}, group code = row mod 64"}
+    out = {"workload": f"{n} x {d} bf16 {what}, top-{k}, group code = row mod 64"}
+    t0 = time.perf_counter()
+    try:
+        idx.partition()
+        out["group_order"] = {"seconds": time.perf_counter() - t0, "rows_in_order": idx.partition_info()[0]}
+    except hvs.HvsError as e:
+        out["group_order"] = {"skipped": str(e)}
     for label, kw, nq, algo, which in (
         ("single_query", {}, 1, "scan", _lib.HVS_PROF_SCAN),
         ("single_query_workspace_filter", {"group_filter": 3}, 1, "scan", _lib.HVS_PROF_SCAN),
@@ -254,8 +264,9 @@ def leg_cfg5(hvs, _lib, torch, dev):
         def f():
             idx.search(qq, k=k, algo=algo, **kw)
 
-        wall = stats_ms(timed_calls(torch, f, 20))
-        kern = stats_ms(kernel_ms(idx, which, f, torch, 20, per_call=True))  # all launches of one call (sample pass + main pass)
+        iters = 20 if n <= 20_000_000 else 8
+        wall = stats_ms(timed_calls(torch, f, iters))
+        kern = stats_ms(kernel_ms(idx, which, f, torch, iters, per_call=True))  # all launches of one call
         live = n // 64 if kw else n
         hbm_floor = live * d * 2 / (HBM_PEAK_GBS * 1e9) * 1e3
         mfma_floor = 2.0 * nq * live * d / (F16_MFMA_PEAK_TFLOPS * 1e12) * 1e3
@@ -269,6 +280,11 @@ def leg_cfg5(hvs, _lib, torch, dev):
         }
     idx.close()
     return out
+
+
+def leg_cfg5_full(hvs, _lib, torch, dev):
+    """The N = 1 anchor of configuration 5: all 100M x 768 bf16 rows (154 GB) on one GPU."""
+    return leg_cfg5(hvs, _lib, torch, dev, n=100_000_000, first_global_row=0, what="table, whole, on one GPU")
 
 
 def leg_clustered(hvs, _lib, torch, dev, batch):
@@ -307,10 +323,149 @@ def leg_clustered(hvs, _lib, torch, dev, batch):
     return out
 
 
+class Watchdog:
+    """N > 1 only.  More than one RCCL rank meets for the first time in the driver's scaling run: if a collective hangs,
+    every rank leaves after `seconds` instead of holding the node, and rank 0 first prints the JSON line with what it has
+    (the headline, once that exists) and the reason."""
+
+    def __init__(self, rank, seconds):
+        import threading
+
+        self.rank, self.seconds, self.result, self.leg = rank, seconds, None, "headline"
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _fire(self):
+        if self.rank == 0 and self.result is not None:
+            self.result.setdefault("aux", {})["watchdog"] = f"no progress within {self.seconds:.0f} s during '{self.leg}': the legs after it are missing"
+            print(json.dumps(self.result), flush=True)
+        print(f"[rank {self.rank}] bench.py watchdog: still in '{self.leg}' after {self.seconds:.0f} s, leaving", file=sys.stderr, flush=True)
+        os._exit(0 if self.rank == 0 and self.result is not None else 3)
+
+    def cancel(self):
+        self._timer.cancel()
+
+
+def sharded_leg(dist, name, fn, *a):
+    """A leg every rank takes part in.  A rank that fails ahead of the leg's collectives must not leave the others waiting
+    in them: set-up errors are agreed on first (`ready`), and the collectives themselves carry a status word."""
+    try:
+        return fn(dist, *a)
+    except Exception as e:  # noqa: BLE001 -- reported in the leg's place
+        import traceback
+
+        traceback.print_exc()
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def all_ready(dist, torch, ok):
+    t = torch.tensor([1 if ok else 0])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def leg_cfg4_sharded(dist, idx, comm, collective, hvs, _lib, torch, dev, total_rows, max_over_ranks):
+    """BASELINE config 4 at N > 1: one Lloyd iteration over the row shards of the resident 10M corpus -- local assignment
+    and partial sums, the all-reduce of sums and counts inside libhvs, the division."""
+    from hirag_prod_amd.sharded import _ptr
+    from hirag_prod_amd._lib import check
+
+    K = 4096
+    tmp = hvs.HvsIndex(DIM, "f32", device=dev.index)
+    tmp.fill_synthetic(K, seed=SEED_CORPUS, first_global_row=0)  # the centroids: global rows 0 .. K-1, regenerated on every rank
+    c = torch.from_numpy(tmp.gather(np.arange(K))).to(dev)
+    tmp.close()
+    walls, assigns, reduces = [], [], []
+    for it in range(4):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        idx.profile(True)
+        idx.profile_reset()
+        assign, sums, counts = idx.kmeans_assign(c)
+        a_ms = idx.profile_get(_lib.HVS_PROF_KMEANS_ASSIGN)[0] + idx.profile_get(_lib.HVS_PROF_KMEANS_UPDATE)[0]
+        idx.profile(False)
+        idx.timer_start()
+        with idx._lock:
+            check(idx._lib.hvs_allreduce_centroids(idx._h, comm._h, _ptr(sums), _ptr(counts), K, 1))
+            check(idx._lib.hvs_sync(idx._h))
+        r_ms = idx.timer_stop()
+        new_c = torch.where((counts > 0).unsqueeze(1), sums / counts.clamp(min=1).unsqueeze(1).float(), c)
+        torch.cuda.synchronize()
+        wall = max_over_ranks((time.perf_counter() - t0) * 1e3)
+        if it:  # the first iteration builds the shard's search-side copy
+            walls.append(wall)
+            assigns.append(a_ms)
+            reduces.append(r_ms)
+    assert int(counts.sum().item()) == total_rows and bool(torch.isfinite(new_c).all().item())
+    return {"workload": f"{total_rows} x {DIM} fp32 rows over {comm.world} GPUs, K = {K}, one Lloyd iteration (assign + partial sums + "
+                        f"all-reduce of {K * DIM * 4 + K * 8} bytes + division)",
+            "transport": collective, "iteration_max_over_ranks": stats_ms(walls), "assign_and_update_rank0": stats_ms(assigns),
+            "all_reduce_rank0": stats_ms(reduces)}
+
+
+def leg_cfg5_sharded(dist, comm, collective, hvs, _lib, torch, dev, rank, world, max_over_ranks):
+    """BASELINE config 5 at N > 1: 100M x 768 bf16 rows split over the GPUs, top-100, 64 workspaces; every shard in group
+    order; one packed all-gather and a merge per call (hvs_search_sharded)."""
+    from hirag_prod_amd.sharded import ShardedSearch, shard_range
+
+    n_total, d, k = int(os.environ.get("BENCH_CFG5_ROWS", "100000000")), 768, 100
+    lo, hi = shard_range(n_total, rank, world)
+    idx, err = None, None
+    try:
+        idx = hvs.HvsIndex(d, "bf16", device=dev.index)
+        idx.reserve(hi - lo)
+        idx.fill_synthetic(hi - lo, seed=SEED_CORPUS, first_global_row=lo, n_groups=64)
+        try:
+            idx.partition()
+        except hvs.HvsError as e:  # device memory for the second set of arrays: the shard keeps the per-row test
+            print(f"[rank {rank}] cfg5 shard stays in arrival order: {e}", file=sys.stderr, flush=True)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if not all_ready(dist, torch, err is None):
+        if idx is not None:
+            idx.close()
+        raise RuntimeError(f"a rank could not set its shard up ({err})")
+    searcher = ShardedSearch.for_index(idx, comm)
+    gen = torch.Generator(device=dev).manual_seed(SEED_QUERY)
+    q = torch.randn((256, d), device=dev, dtype=torch.float32, generator=gen)
+    out = {"workload": f"{n_total} x {d} bf16 rows over {world} GPUs ({hi - lo} per GPU), top-{k}, group code = row mod 64",
+           "transport": collective, "rows_in_group_order_rank0": idx.partition_info()[0]}
+    for label, kw, nq, algo in (("single_query", {}, 1, "scan"), ("single_query_workspace_filter", {"group_filter": 3}, 1, "scan"),
+                                ("batch_256", {}, 256, "mfma"), ("batch_256_workspace_filter", {"group_filter": 3}, 256, "mfma")):
+        qq = q[:nq].contiguous()
+        for _ in range(3):
+            searcher.search(qq, k, algo=algo, **kw)
+        walls = []
+        idx.profile(True)
+        idx.profile_reset()
+        for _ in range(12):
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            dd, ii, cc = searcher.search(qq, k, algo=algo, **kw)
+            torch.cuda.synchronize()
+            walls.append(max_over_ranks((time.perf_counter() - t0) * 1e3))
+        scan_ms, scan_n = idx.profile_get(_lib.HVS_PROF_SCAN)
+        mfma_ms, mfma_n = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)
+        merge_ms, merge_n = idx.profile_get(_lib.HVS_PROF_MERGE)
+        idx.profile(False)
+        assert int(cc.min().item()) == k and bool((dd[:, 1:] >= dd[:, :-1]).all().item())
+        if kw:
+            assert bool((ii % 64 == 3).all().item())
+        out[label] = {"call_max_over_ranks": stats_ms(walls), "qps": nq * 1e3 / float(np.median(walls)),
+                      "search_kernels_ms_per_call_rank0": (scan_ms + mfma_ms) / 12, "merges_ms_per_call_rank0": merge_ms / 12,
+                      "all_gather_bytes_per_rank": nq * (k * 12 + 4)}
+    dist.barrier()
+    idx.close()
+    return out
+
+
 # Per-configuration legs that fill a table of their own: each runs in a child process after the headline table is
 # freed, so that whatever happens in one of them (a failed assertion, a device fault that ends its process) costs that
 # leg and nothing else -- the parent prints the one JSON line either way.
-CHILD_LEGS = {"cfg2": leg_cfg2, "cfg5_shard": leg_cfg5, "clustered": leg_clustered}
+CHILD_LEGS = {"cfg2": leg_cfg2, "cfg5_shard": leg_cfg5, "cfg5_full": leg_cfg5_full, "clustered": leg_clustered}
 
 
 def run_child_leg(name, batch):
@@ -388,16 +543,29 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # torch.distributed carries a 128-byte rendezvous token, the timing barriers and the max over ranks of one float: a gloo
+    # group over CPU tensors does all three.  No "nccl" group is opened, so the RCCL communicator inside libhvs is the only
+    # one this process ever forms.
+    if world > 1:
+        from datetime import timedelta
+
+        dist.init_process_group("gloo", timeout=timedelta(seconds=900))
+        print(f"[rank {rank}] process group backend: {dist.get_backend()}", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         if world > 1:  # a launcher on a box without a GPU: meet the other ranks, then say what is missing
-            dist.init_process_group("gloo")
             dist.barrier()
             dist.destroy_process_group()
         raise SystemExit("bench.py: no HIP device visible (this benchmark has no CPU path)")
+    if os.environ.get("BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a one-GPU box: every rank on GPU 0, where no RCCL
+        local_rank = 0                      # communicator can form, so the exchange runs host-staged over the gloo group
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    watchdog = Watchdog(rank, float(os.environ.get("BENCH_WATCHDOG_S", "1500"))) if world > 1 else None
+
+    def max_over_ranks(value):
+        t = torch.tensor([value], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import hirag_prod_amd as hvs
     from hirag_prod_amd import _lib
@@ -413,12 +581,12 @@ def main():
             collective = "rccl (ncclAllGather in libhvs)"
         except hvs.HvsError as e:
             print(f"[rank {rank}] RCCL communicator failed ({e}); falling back to the host-staged transport", file=sys.stderr, flush=True)
-        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        ok = torch.tensor([1 if comm is not None else 0])
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if comm is not None:
                 comm.close()
-            comm = HvsComm.from_process_group(device=local_rank, group=dist.new_group(backend="gloo"), transport="host")
+            comm = HvsComm.from_process_group(device=local_rank, transport="host")
             collective = "host-staged over gloo (RCCL communicator could not be formed)"
 
     lo, hi = shard_range(args.rows, rank, world)
@@ -451,9 +619,7 @@ def main():
     kern_ms, kern_n = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)
     idx.profile(False)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
 
     # median / p95 of single steps, each synchronised on its own (outside the timed region above)
     step_stats = stats_ms(timed_calls(torch, step, min(max(args.steps, 5), 10), warm=0)) if world == 1 else None
@@ -494,6 +660,7 @@ def main():
                 "k": TOPK,
                 "parallelism": f"row-shard x{world}",
                 "collective": collective,
+                "process_group": "gloo (rendezvous token, barriers, max over ranks)" if world > 1 else None,
             },
             "roofline": {
                 "bound": "mfma",
@@ -510,6 +677,8 @@ def main():
             },
         }
 
+    if watchdog is not None:
+        watchdog.result = result  # from here on a hang costs the legs below, not the headline
     # single-query (GEMV, HBM-bound) figures on the same resident shard, outside the timed region
     if not args.no_aux:
         q1 = queries[:1].contiguous()
@@ -559,9 +728,7 @@ def main():
             sms, sn = idx.profile_get(_lib.HVS_PROF_SCAN)
             idx.profile(False)
             if world > 1:
-                t = torch.tensor([e2], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                e2 = float(t.item())
+                e2 = max_over_ranks(e2)
             per = kms / max(kn, 1)
             alg = 2.0 * args.batch * (hi - lo) * DIM / (per * 1e-3) / 1e12
             return {
@@ -603,7 +770,9 @@ def main():
         if rank == 0:
             result["aux"]["single_query_auto"] = {
                 "qps": 20 / e4, "ms_per_query": e4 / 20 * 1e3,
-                "fp32_row_bytes_per_s_over_hbm_peak": (hi - lo) * DIM * 4 / (e4 / 20) / (HBM_PEAK_GBS * 1e9),
+                # the route streams the fp16 hi slabs of the split copy: 2 bytes per element, half the fp32 rows
+                "bytes_streamed_per_query": (hi - lo) * ((DIM + 63) // 64 * 64) * 2,
+                "streamed_bytes_per_s_over_hbm_peak": (hi - lo) * ((DIM + 63) // 64 * 64) * 2 / (e4 / 20) / (HBM_PEAK_GBS * 1e9),
                 "ids_equal_to_scan": float((i_auto == i_scan).float().mean().item()),
                 "max_abs_score_diff_vs_scan": float((d_auto - d_scan).abs().max().item()),
             }
@@ -647,13 +816,26 @@ def main():
 
     if world == 1 and not args.no_aux:
         aux_leg("cfg4_kmeans", leg_cfg4, idx, hvs, _lib, torch, dev, hi - lo)
+    if world > 1 and not args.no_aux:
+        watchdog.leg = "cfg4_kmeans over the shards"
+        out4 = sharded_leg(dist, "cfg4_kmeans", leg_cfg4_sharded, idx, comm, collective, hvs, _lib, torch, dev, args.rows, max_over_ranks)
+        if rank == 0:
+            result["aux"]["cfg4_kmeans"] = out4
     if world > 1:
         dist.barrier()
     idx.close()
+    if world > 1 and not args.no_aux:
+        torch.cuda.empty_cache()
+        watchdog.leg = "cfg5 over the shards"
+        out5 = sharded_leg(dist, "cfg5", leg_cfg5_sharded, comm, collective, hvs, _lib, torch, dev, rank, world, max_over_ranks)
+        if rank == 0:
+            result["aux"]["cfg5"] = out5
     if world == 1 and not args.no_aux:
         torch.cuda.empty_cache()
-        for name in ("cfg2", "cfg5_shard", "clustered"):
+        for name in ("cfg2", "cfg5_shard", "clustered", "cfg5_full"):
             result["aux"][name] = child_leg(name, args.batch)
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

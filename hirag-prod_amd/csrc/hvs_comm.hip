@@ -66,6 +66,20 @@ int rccl_load() {
     HVS_SYM(GroupEnd, "ncclGroupEnd");
     HVS_SYM(GetErrorString, "ncclGetErrorString");
 #undef HVS_SYM
+    // the streams this library hands to RCCL belong to the HIP runtime libhvs is bound to: RCCL must be bound to the same
+    // one (a process can hold two -- PyTorch's wheel carries its own -- and which of them a library gets depends on
+    // SONAMEs and load order)
+    if (!getenv("HVS_RCCL_ANY_HIP")) {
+        Dl_info theirs, ours;
+        void *sym = dlsym(h, "hipStreamCreate");
+        if (sym && dladdr(sym, &theirs) && dladdr((void *)&hipStreamCreate, &ours) && theirs.dli_fname && ours.dli_fname &&
+            strcmp(theirs.dli_fname, ours.dli_fname) != 0) {
+            hvs_set_error("hvs_comm_init: RCCL is bound to the HIP runtime %s, this library to %s; their streams are not interchangeable "
+                          "(HVS_RCCL_PATH picks another RCCL, HVS_RCCL_ANY_HIP=1 skips this check)", theirs.dli_fname, ours.dli_fname);
+            dlclose(h);
+            return 1;
+        }
+    }
     g_rccl.handle = h;
     return 0;
 }
@@ -177,8 +191,21 @@ extern "C" int hvs_comm_info(hvs_comm *c, int *rank, int *world, int *is_rccl) {
 
 static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// One packed record per rank: [nq, k] distances | [nq, k] ids | [nq] counts, each part 256-byte aligned, so that ONE
-// all-gather moves everything the merge needs.
+__global__ void any_status_kernel(const char *records, size_t rec, size_t o_status, int W, int *out) {
+    int bad = -1;
+    for (int r = threadIdx.x; r < W; r += blockDim.x)
+        if (*reinterpret_cast<const int *>(records + (size_t)r * rec + o_status) != 0) bad = r;
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(bad, off);
+        bad = o > bad ? o : bad;
+    }
+    if (threadIdx.x == 0) *out = bad;  // the highest rank that reported a failure, -1 for none
+}
+
+// One packed record per rank: [nq, k] distances | [nq, k] ids | [nq] counts | status, each part 256-byte aligned, so
+// that ONE all-gather moves everything the merge needs.  A rank whose local search fails still enters the collective
+// (with empty lists and a non-zero status word), so that the others are not left waiting in it; every rank then returns
+// an error.  What cannot be covered: a rank that fails before it has the staging buffer the collective receives into.
 extern "C" int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *queries, int nq, int fold, int k,
                                   int32_t group_filter, const uint32_t *row_mask, double max_distance, float *out_dist,
                                   int64_t *out_ids, int32_t *out_count, int on_device, int algo) {
@@ -191,7 +218,8 @@ extern "C" int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *q
                 comm->device, idx->device);
     HVS_HIP(hipSetDevice(idx->device));
     const int W = comm->world;
-    const size_t o_ids = up256((size_t)nq * k * 4), o_cnt = o_ids + up256((size_t)nq * k * 8), rec = o_cnt + up256((size_t)nq * 4);
+    const size_t o_ids = up256((size_t)nq * k * 4), o_cnt = o_ids + up256((size_t)nq * k * 8), o_status = o_cnt + up256((size_t)nq * 4),
+                 rec = o_status + 256;
     // staging (workspace 3, which a search with device buffers leaves alone):
     // [W records][merged outputs, if they go to the host][queries and mask, if they come from the host]
     const size_t o_out = (size_t)W * rec;
@@ -213,11 +241,28 @@ extern "C" int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *q
     }
     // the local top-k lands in this rank's record
     char *mine = base + (size_t)comm->rank * rec;
-    HVS_TRY(hvs_search(idx, d_q, nq, fold, k, group_filter, d_mask, max_distance, 0, -1, (float *)mine, (int64_t *)(mine + o_ids),
-                       (int32_t *)(mine + o_cnt), 1, algo));
+    int local_rc = hvs_search(idx, d_q, nq, fold, k, group_filter, d_mask, max_distance, 0, -1, (float *)mine, (int64_t *)(mine + o_ids),
+                              (int32_t *)(mine + o_cnt), 1, algo);
+    if (const char *e = getenv("HVS_TEST_FAIL_RANK"))  // tests: this rank's local search counts as failed
+        if (local_rc == 0 && atoi(e) == comm->rank) {
+            hvs_set_error("hvs_search_sharded: local search failed on purpose (HVS_TEST_FAIL_RANK)");
+            local_rc = 2;
+        }
+    const std::string local_err = local_rc ? hvs_last_error() : "";
+    if (local_rc) HVS_HIP(hipMemsetAsync(mine + o_cnt, 0, (size_t)nq * 4, idx->stream));  // empty lists
+    HVS_HIP(hipMemsetAsync(mine + o_status, local_rc ? 1 : 0, 4, idx->stream));
+    int failed_rank = local_rc ? comm->rank : -1;
     if (W > 1 || comm->nccl) {  // a one-rank RCCL communicator still runs its (trivial) collective: same code path at every size
         if (comm->nccl) {
             HVS_NCCL(g_rccl.AllGather(mine, base, rec, ncclChar, comm->nccl, idx->stream));  // in place: send = recv + rank * rec
+            void *h = nullptr;
+            HVS_TRY(comm_pinned(comm, 256, &h));
+            int *d_flag = (int *)(base + (size_t)comm->rank * rec + o_status + 64);  // spare bytes of this rank's own status slot
+            any_status_kernel<<<1, 64, 0, idx->stream>>>(base, rec, o_status, W, d_flag);
+            HVS_HIP(hipGetLastError());
+            HVS_HIP(hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, idx->stream));
+            HVS_HIP(hipStreamSynchronize(idx->stream));
+            failed_rank = *(const int *)h;
         } else {
             void *h = nullptr;
             HVS_TRY(comm_pinned(comm, (size_t)(W + 1) * rec, &h));
@@ -226,9 +271,16 @@ extern "C" int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *q
             HVS_HIP(hipStreamSynchronize(idx->stream));
             const int rc = comm->allgather(comm->ctx, h_send, h, rec);
             HVS_REQUIRE(rc == 0, "hvs_search_sharded: the all-gather callback failed with status %d", rc);
+            for (int r = 0; r < W; r++)
+                if (*(const int *)((const char *)h + (size_t)r * rec + o_status) != 0) failed_rank = r;
             HVS_HIP(hipMemcpyAsync(base, h, (size_t)W * rec, hipMemcpyHostToDevice, idx->stream));
         }
     }
+    if (local_rc) {
+        hvs_set_error("%s", local_err.c_str());
+        return local_rc;
+    }
+    HVS_REQUIRE(failed_rank < 0, "hvs_search_sharded: the local search of rank %d failed (its own error message says why)", failed_rank);
     float *m_dist = on_device ? out_dist : (float *)(base + o_out);
     int64_t *m_ids = on_device ? out_ids : (int64_t *)(base + o_out + o_ids);
     int32_t *m_cnt = on_device ? out_count : (int32_t *)(base + o_out + o_cnt);

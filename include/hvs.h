@@ -321,7 +321,8 @@ int hvs_merge_topk(int device_id, void *stream, const float *in_dist, const int6
  * hvs_comm_unique_id: rank 0 makes the HVS_UNIQUE_ID_BYTES rendezvous token (ncclGetUniqueId) and the caller hands it
  * to every rank by whatever channel it has (a file, MPI, torch.distributed).  hvs_comm_init: ncclCommInitRank on
  * device_id -- RCCL over xGMI, the product transport; collective on all ranks.  librccl is opened on first use
- * (HVS_RCCL_PATH, $ROCM_PATH/lib, /opt/rocm/lib).
+ * (HVS_RCCL_PATH, $ROCM_PATH/lib, /opt/rocm/lib) and must be bound to the same HIP runtime as this library, which the
+ * call checks (a process can hold two; HVS_RCCL_ANY_HIP=1 skips the check).
  * hvs_comm_init_host: the same exchanges through two caller-supplied functions over HOST buffers, for ranks that cannot
  * form an RCCL communicator (processes sharing one GPU, a process group without device collectives).
  *   allgather(ctx, send, recv, bytes): every rank contributes `bytes` bytes; recv = the W contributions in rank order.
@@ -346,6 +347,12 @@ int hvs_comm_info(hvs_comm *comm, int *rank, int *world, int *is_rccl);
  * ONE all-gather of every rank's packed (distances, ids, counts) record -- k * 12 + 4 bytes per query and rank -- and a
  * k-way merge by (distance, id) on every rank, all on the index's stream.  Every rank calls it with the same queries and
  * gets the same answer, which equals the single-index answer over the whole table.  Collective.
+ * A rank whose local search fails (device memory for a workspace, say) still enters the all-gather, with empty lists and
+ * a status word in its record; every rank then returns an error (the failing rank its own, the others one that names
+ * it), and the communicator stays usable.  What this cannot cover is a rank that fails before it holds the buffer the
+ * all-gather receives into (arguments the ranks disagree on, no memory for the staging itself): the other ranks then
+ * wait in the collective, and the communicator is lost.  To read the status words the call waits for the all-gather,
+ * so with on_device = 1 only the merge is still in flight when it returns.
  */
 int hvs_search_sharded(hvs_index *idx, hvs_comm *comm, const float *queries, int nq, int fold, int k,
                        int32_t group_filter, const uint32_t *row_mask, double max_distance,

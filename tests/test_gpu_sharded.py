@@ -125,6 +125,56 @@ def test_two_processes_on_one_gpu_exchange_through_the_host_transport(tmp_path):
     assert [(int(r["lo"]), int(r["hi"])) for r in ranks] == [(0, 20_002), (20_002, 40_003)]
 
 
+def test_eight_processes_on_one_gpu_at_k_100(tmp_path):
+    """The record strides and the 8-way merge of hvs_search_sharded as the 8-GPU run uses them (k = 100, one rank without
+    a row, one with fewer rows than k, a filter that leaves a third without a result), through the host transport; and a
+    rank whose local search fails: every rank gets an error instead of waiting in the exchange, and the next call works."""
+    import socket
+
+    import hirag_prod_amd as hvs
+    from hirag_prod_amd.sharded import ShardedSearch
+    from tests import sharded_worker as w
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 8
+    procs = [_run(["eight_ranks", r, world, port, tmp_path / f"rank{r}.npz"], 400) for r in range(world)]
+    logs = []
+    for p, timeout in procs:
+        try:
+            logs.append(p.communicate(timeout=timeout)[0])
+        except Exception:
+            for q_, _ in procs:
+                q_.kill()
+            raise
+    for (p, _), log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    rows, q, groups = w.eight_corpus()
+    idx = hvs.HvsIndex(w.EIGHT_DIM, "f16")
+    idx.add(rows, group_codes=groups)
+    one = w.eight_searches(ShardedSearch.for_index(idx), q, torch)
+    after = idx.search(q[:2], k=10, algo="scan")[1]
+    idx.close()
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for r, got in enumerate(ranks):
+        for name in ("scan", "auto", "group0_host", "k10"):
+            for part in ("_d", "_i", "_c"):
+                assert np.array_equal(got[name + part].view(np.uint8), one[name + part].view(np.uint8)), f"rank {r}: {name}{part} differs from the one-index answer"
+        assert int(got["failure_seen"]) == 1 and int(got["failure_names_rank"]) == 1, f"rank {r} did not see rank 5's failure"
+        assert np.array_equal(got["after_failure_i"], after)
+    got = ranks[0]
+    for j in range(5):
+        parity.check_topk(got["scan_d"][j], got["scan_i"][j], got["scan_c"][j], parity.full_distances(rows, q[j], "f16"), w.EIGHT_K, label=f"8 ranks scan q={j}")
+    for j in range(q.shape[0]):
+        parity.check_topk(got["auto_d"][j], got["auto_i"][j], got["auto_c"][j], parity.full_distances(rows, q[j], "f16"), w.EIGHT_K, threshold=0.97,
+                          label=f"8 ranks auto q={j}")
+    for j in range(q.shape[0] // 2):
+        parity.check_topk(got["group0_host_d"][j], got["group0_host_i"][j], got["group0_host_c"][j],
+                          parity.full_distances(rows, q[2 * j : 2 * j + 2], "f16"), w.EIGHT_K, keep=groups == 0, label=f"8 ranks filter q={j}")
+    assert got["scan_i"][0][:2].tolist() == [17, 12010]  # the tie across shards: lower global id first
+
+
 def test_rccl_communicator_of_one_rank(tmp_path):
     """ncclCommInitRank / ncclAllGather / ncclAllReduce inside libhvs on real hardware (one rank: all a one-GPU box
     allows), in a process of its own so that trouble in the collective library cannot take the test run down."""

@@ -140,6 +140,8 @@ def test_bench_argument_path_for_two_gpus_stops_at_the_device(tmp_path):
                        capture_output=True, text=True, timeout=600)
     # both ranks parsed their arguments, read RANK / WORLD_SIZE, met in a process group and stopped at the missing device
     assert r.returncode != 0 and (r.stderr + r.stdout).count("no HIP device visible") >= 2, (r.stderr + r.stdout)[-2000:]
+    # the process group is gloo (token, barriers, a max over ranks): libhvs's RCCL communicator is the only one a rank ever forms
+    assert (r.stderr + r.stdout).count("process group backend: gloo") == 2, (r.stderr + r.stdout)[-2000:]
 
 
 def test_shard_range_covers_rows():
