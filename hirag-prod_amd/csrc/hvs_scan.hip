@@ -1286,81 +1286,66 @@ int hvs_range_search_core(hvs_index *idx, const float *queries, int fold, int32_
 
 // ---- cross-GPU merge ----------------------------------------------------------------------------
 // (dist, id) lists -> keys are not usable here (ids are 64-bit), so this kernel orders pairs directly.
-// One wave per query; candidates = P*k pairs; selection by rank counting in chunks through LDS.
 // List pl of query q starts at in_dist[q * dist_q + pl * dist_p] (likewise ids and counts): [nq, P, k] arrays and the
 // per-rank records of a packed all-gather are both such layouts.
+// One block per query.  Every list is ascending and ids are unique across lists, so an entry's place in the union is
+// its own index plus, for every other list, the number of entries ordered before it -- a binary search per list; the
+// entries whose place is below k are written there.  (A wave inserting the P k candidates one by one into a sorted list
+// took 1.6 ms for 256 queries, k = 100, P = 2: more than the search it followed.)
 struct MergeStrides {
     int64_t dist_q, dist_p, ids_q, ids_p, cnt_q, cnt_p;
 };
-__global__ __launch_bounds__(64) void merge_pairs_kernel(const float *__restrict__ in_dist, const int64_t *__restrict__ in_ids,
-                                                          const int32_t *__restrict__ in_count, int P, int k, MergeStrides ms,
-                                                          float *out_dist, int64_t *out_ids, int32_t *out_count) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS: sorted list of k (dist, id) pairs
-    volatile float *Ld = reinterpret_cast<volatile float *>(smem);
-    volatile int64_t *Li = reinterpret_cast<volatile int64_t *>(smem + (((size_t)k * 4 + 15) & ~(size_t)15));
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void merge_pairs_kernel(const float *__restrict__ in_dist, const int64_t *__restrict__ in_ids,
+                                                           const int32_t *__restrict__ in_count, int P, int k, MergeStrides ms,
+                                                           float *out_dist, int64_t *out_ids, int32_t *out_count) {
+    __shared__ int s_cnt[64];  // P <= 64 lists
     const int q = blockIdx.x;
-    int cnt = 0;
-    for (int pl = 0; pl < P; pl++) {
+    for (int pl = threadIdx.x; pl < P; pl += blockDim.x) {
         int c = in_count[(int64_t)q * ms.cnt_q + (int64_t)pl * ms.cnt_p];
-        c = c < 0 ? 0 : (c > k ? k : c);  // a count is data from another rank: never index past a list
-        const float *sd = in_dist + (int64_t)q * ms.dist_q + (int64_t)pl * ms.dist_p;
-        const int64_t *si = in_ids + (int64_t)q * ms.ids_q + (int64_t)pl * ms.ids_p;
-        for (int base = 0; base < c; base += 64) {
-            const int i = base + lane;
-            const bool have = i < c;
-            const float d = have ? sd[i] : __builtin_inff();
-            const int64_t id = have ? si[i] : 0x7FFFFFFFFFFFFFFFll;
-            uint64_t pending = __ballot(have);
-            while (pending) {
-                const int src = __ffsll((unsigned long long)pending) - 1;
-                pending &= pending - 1;
-                const float cd = __shfl(d, src);
-                const int64_t cid = ((int64_t)__shfl((int)(id >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)id, src);
-                // position = number of entries ordered before (cd, cid)
-                int pos = 0;
-                for (int b2 = 0; b2 < cnt; b2 += 64) {
-                    const int j = b2 + lane;
-                    bool lt = false;
-                    if (j < cnt) {
-                        const float ld = Ld[j];
-                        const int64_t li = Li[j];
-                        lt = ld < cd || (ld == cd && li < cid);
-                    }
-                    pos += __popcll(__ballot(lt));
-                }
-                if (pos >= k) continue;
-                const int newcnt = cnt < k ? cnt + 1 : k;
-                for (int b2 = ((newcnt - 1) >> 6) << 6; b2 >= ((pos >> 6) << 6); b2 -= 64) {
-                    const int j = b2 + lane;
-                    float vd = 0.0f;
-                    int64_t vi = 0;
-                    bool w = false;
-                    if (j > pos && j < newcnt) { vd = Ld[j - 1]; vi = Li[j - 1]; w = true; }
-                    else if (j == pos) { vd = cd; vi = cid; w = true; }
-                    wave_fence();
-                    if (w) { Ld[j] = vd; Li[j] = vi; }
-                    wave_fence();
-                }
-                cnt = newcnt;
+        s_cnt[pl] = c < 0 ? 0 : (c > k ? k : c);  // a count is data from another rank: never index past a list
+    }
+    __syncthreads();
+    int total = 0;
+    for (int pl = 0; pl < P; pl++) total += s_cnt[pl];
+    for (int t = threadIdx.x; t < P * k; t += blockDim.x) {
+        const int pl = t / k, i = t - pl * k;
+        if (i >= s_cnt[pl]) continue;
+        const float d = in_dist[(int64_t)q * ms.dist_q + (int64_t)pl * ms.dist_p + i];
+        const int64_t id = in_ids[(int64_t)q * ms.ids_q + (int64_t)pl * ms.ids_p + i];
+        int rank = i;
+        for (int o = 0; o < P && rank < k; o++) {
+            if (o == pl) continue;
+            const float *od = in_dist + (int64_t)q * ms.dist_q + (int64_t)o * ms.dist_p;
+            const int64_t *oi = in_ids + (int64_t)q * ms.ids_q + (int64_t)o * ms.ids_p;
+            int lo = 0, hi = s_cnt[o];  // entries of list o ordered before (d, id)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float md = od[mid];
+                const int64_t mi = oi[mid];
+                if (md < d || (md == d && (mi < id || (mi == id && o < pl)))) lo = mid + 1;  // (an id present in two lists: the lower list first)
+                else hi = mid;
             }
+            rank += lo;
+        }
+        if (rank < k) {
+            out_dist[(size_t)q * k + rank] = d;
+            out_ids[(size_t)q * k + rank] = id;
         }
     }
-    wave_fence();
-    for (int i = lane; i < k; i += 64) {
-        out_dist[(size_t)q * k + i] = i < cnt ? Ld[i] : __builtin_inff();
-        out_ids[(size_t)q * k + i] = i < cnt ? Li[i] : -1;
+    const int kept = total < k ? total : k;
+    for (int i = kept + threadIdx.x; i < k; i += blockDim.x) {
+        out_dist[(size_t)q * k + i] = __builtin_inff();
+        out_ids[(size_t)q * k + i] = -1;
     }
-    if (lane == 0) out_count[q] = cnt;
+    if (threadIdx.x == 0) out_count[q] = kept;
 }
 
 int hvs_merge_launch(hipStream_t st, const float *in_dist, const int64_t *in_ids, const int32_t *in_count, int nq, int P, int k,
                      int64_t dist_q, int64_t dist_p, int64_t ids_q, int64_t ids_p, int64_t cnt_q, int64_t cnt_p, float *out_dist,
                      int64_t *out_ids, int32_t *out_count) {
-    const size_t lds = (((size_t)k * 4 + 15) & ~(size_t)15) + (size_t)k * 8;
+    HVS_REQUIRE(P >= 1 && P <= 64, "merge: %d lists per query, at most 64", P);
     const MergeStrides ms{dist_q, dist_p, ids_q, ids_p, cnt_q, cnt_p};
-    merge_pairs_kernel<<<nq, 64, lds, st>>>(in_dist, in_ids, in_count, P, k, ms, out_dist, out_ids, out_count);
+    merge_pairs_kernel<<<nq, 256, 0, st>>>(in_dist, in_ids, in_count, P, k, ms, out_dist, out_ids, out_count);
     HVS_HIP(hipGetLastError());
     return 0;
 }
