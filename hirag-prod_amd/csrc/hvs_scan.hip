@@ -612,7 +612,7 @@ static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int n
     return 0;
 }
 
-// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq*ceil(P/32)*k keys.
+// reduce [nq, P, k] key lists (in bufA) to final outputs; bufB is scratch of at least nq * ceil(P / MERGE_FAN) * k keys.
 // positions: d_ids receives row positions instead of external ids
 int hvs_reduce_lists(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                      int64_t *d_ids, int32_t *d_count, bool positions) {

@@ -129,3 +129,98 @@ def test_limits_are_refused_with_a_message(hvs):
     _same(ref, got, "after a refusal")
     idx.close()
     small.close()
+
+
+def test_limit_on_a_full_grid_is_the_documented_one(hvs):
+    """4096 wave lists (4 waves x 1024 resident blocks): k * 8 bytes * 1.125 per list must fit 7 MiB, i.e. k <= 199"""
+    lib = hvs.load_library()
+    rng = np.random.default_rng(6)
+    n, d = 300_000, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    idx = hvs.HvsIndex(d, "f32")
+    idx.add(rows)
+    q_host = rng.standard_normal((2, d)).astype(np.float32)
+    q = torch.from_numpy(q_host).cuda()
+    ref, got = _both(hvs, idx, q, 2, 1, 199)
+    _same(ref, got, "k = 199")
+    parity.check_topk(got[0][1], got[1][1], got[2][1], parity.full_distances(rows, q_host[1], "f32"), 199, label="k = 199")
+    dist = torch.empty((2, 200), dtype=torch.float32, device="cuda")
+    ids = torch.empty((2, 200), dtype=torch.int64, device="cuda")
+    cnt = torch.empty((2,), dtype=torch.int32, device="cuda")
+    rc = lib.hvs_search_noalloc(idx._h, _ptr(q), 2, 1, 200, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
+    assert rc != 0 and b"scratch" in lib.hvs_last_error()
+    idx.close()
+
+
+def test_a_table_in_group_order_answers_from_the_row_range(hvs):
+    rng = np.random.default_rng(8)
+    n, d = 120_000, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    groups = rng.integers(0, 9, n).astype(np.int32)
+    idx = hvs.HvsIndex(d, "f16")
+    idx.add(rows, group_codes=groups)
+    q_host = rng.standard_normal((3, d)).astype(np.float32)
+    q = torch.from_numpy(q_host).cuda()
+    before = _both(hvs, idx, q, 3, 1, 20, group=4)[1]
+    idx.partition()
+    ref, got = _both(hvs, idx, q, 3, 1, 20, group=4)
+    _same(ref, got, "group range")
+    _same(before, got, "before and after the partition")
+    for i in range(3):
+        parity.check_topk(got[0][i], got[1][i], got[2][i], parity.full_distances(rows, q_host[i], "f16"), 20, keep=groups == 4,
+                          label=f"group range q={i}")
+    # rows behind the ordered part: the call keeps the per-row test over the whole table (no room for a second list)
+    extra = rng.standard_normal((500, d)).astype(np.float32)
+    idx.add(extra, ids=np.arange(n, n + 500), group_codes=np.full(500, 4, np.int32))
+    ref, got = _both(hvs, idx, q, 3, 1, 20, group=4)
+    _same(ref, got, "group range + tail")
+    all_rows = np.concatenate([rows, extra])
+    keep = np.concatenate([groups == 4, np.ones(500, bool)])
+    for i in range(3):
+        parity.check_topk(got[0][i], got[1][i], got[2][i], parity.full_distances(all_rows, q_host[i], "f16"), 20, keep=keep,
+                          label=f"tail q={i}")
+    idx.close()
+
+
+def test_the_call_can_be_captured_into_a_graph(hvs):
+    """what the entry point is for: a caller that records its launches (no allocation may happen while it does)"""
+    lib = hvs.load_library()
+    rng = np.random.default_rng(9)
+    n, d, nq, k = 50_000, 96, 4, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    stream = torch.cuda.Stream()
+    idx = hvs.HvsIndex(d, "f16", stream=stream.cuda_stream)
+    idx.add(rows)
+    q_host = rng.standard_normal((nq, d)).astype(np.float32)
+    q = torch.from_numpy(q_host).cuda()
+    dist = torch.full((nq, k), -7.0, dtype=torch.float32, device="cuda")
+    ids = torch.full((nq, k), -7, dtype=torch.int64, device="cuda")
+    cnt = torch.full((nq,), -7, dtype=torch.int32, device="cuda")
+
+    def call():
+        rc = lib.hvs_search_noalloc(idx._h, _ptr(q), nq, 1, k, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
+        assert rc == 0, lib.hvs_last_error()
+
+    call()  # once outside: kernel attributes are set on first use
+    idx.sync()
+    expect = (dist.cpu().numpy().copy(), ids.cpu().numpy().copy(), cnt.cpu().numpy().copy())
+    dist.fill_(-7.0)
+    ids.fill_(-7)
+    cnt.fill_(-7)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        call()
+    assert float(dist[0, 0].item()) == -7.0, "capturing must record the launches, not run them"
+    q.copy_(torch.from_numpy(q_host[::-1].copy()))  # new inputs in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    for i in range(nq):
+        parity.check_topk(dist[i].cpu().numpy(), ids[i].cpu().numpy(), cnt[i].cpu().numpy(), parity.full_distances(rows, q_host[nq - 1 - i], "f16"), k,
+                          label=f"replayed q={i}")
+    q.copy_(torch.from_numpy(q_host))
+    graph.replay()
+    torch.cuda.synchronize()
+    _same(expect, (dist.cpu().numpy(), ids.cpu().numpy(), cnt.cpu().numpy()), "replay with the first inputs")
+    del graph
+    idx.close()
