@@ -106,6 +106,27 @@ int main(void) {
     if (total < want || total > maybe) return 8;
     for (int64_t i = 0; i < total; i++)
         if (groups[ri[i]] != 2 || rd[i] >= 0.9f || (i && ri[i] <= ri[i - 1])) return 9;
+
+    /* the table in group order: WHERE group = 2 becomes a row range; ids travel with their rows, so the answers name
+       the same rows as a search of the table in arrival order */
+    {
+        float d_before[40 * K], d_after[40 * K];
+        int64_t i_before[40 * K], i_after[40 * K];
+        int32_t c_before[40], c_after[40];
+        static int64_t old_pos[N];
+        int64_t n_after = 0, ordered = 0, n_groups = 0;
+        CK(hvs_search(idx, &queries[0][0], 40, 1, K, 2, NULL, INFINITY, 0, -1, d_before, i_before, c_before, 0, HVS_ALGO_MFMA));
+        CK(hvs_index_partition(idx, 0, &n_after, old_pos));
+        CK(hvs_index_partition_info(idx, &ordered, &n_groups));
+        if (n_after != N || ordered != N || n_groups != 4) return 12;
+        for (int64_t i = 1; i < N; i++)
+            if (groups[old_pos[i]] < groups[old_pos[i - 1]] || (groups[old_pos[i]] == groups[old_pos[i - 1]] && old_pos[i] < old_pos[i - 1])) return 13;
+        CK(hvs_search(idx, &queries[0][0], 40, 1, K, 2, NULL, INFINITY, 0, -1, d_after, i_after, c_after, 0, HVS_ALGO_MFMA));
+        if (memcmp(i_before, i_after, sizeof(i_after)) || memcmp(d_before, d_after, sizeof(d_after)) || memcmp(c_before, c_after, sizeof(c_after))) return 14;
+        for (int q = 0; q < 40; q++)
+            for (int j = 0; j < K; j++)
+                if (groups[i_after[q * K + j]] != 2 || fabs(ref[q][i_after[q * K + j]] - d_after[q * K + j]) > 1e-5) return 15;
+    }
     CK(hvs_index_destroy(idx));
 
     /* a path 0 - 1 - 2 - 3 plus a self loop on 3; nodes 0 and 2 are chunks; seed on node 1 */

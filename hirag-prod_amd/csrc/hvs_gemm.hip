@@ -617,7 +617,7 @@ __device__ __forceinline__ void publish_pooled(const SearchParams &p, const Bloc
 
 // One wave per query: the k smallest keys of its pooled list, ascending, as distances / ids / count.  Lists of up to
 // 1024 keys are ranked in registers in one go; longer ones in rounds that carry the best k so far at the list's front.
-template <int KL>
+template <int KL, int ROUND>
 __global__ __launch_bounds__(64) void select_pooled_kernel(uint64_t *__restrict__ lists, const unsigned int *__restrict__ counts, size_t slots,
                                                             int k, const int64_t *__restrict__ ids, float *__restrict__ out_dist,
                                                             int64_t *__restrict__ out_ids, int32_t *__restrict__ out_count) {
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(64) void select_pooled_kernel(uint64_t *__restrict_
     int have = 0;      // keys at the list's front that are the best of everything read so far
     size_t pos = 0;    // next unread key
     while (pos < n) {
-        constexpr int ROUND = CAND_MAX;
+        static_assert(ROUND > 64 * KL, "a round must bring new keys in next to the k it carries");
         const int take = (int)((n - pos) < (size_t)(ROUND - have) ? (n - pos) : (size_t)(ROUND - have));
         const int cnt = have + take;
         if (cnt > k) {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
     const unsigned long long c_pub = (p.dbg & 512) ? clock64() : 0;
 #endif
     __syncthreads();
-    if (XCHG && p.pooled_count) publish_pooled<FOLD, T>(p, b, qt * (BM / FOLD), wave, lane);
+    if (p.pooled_count) publish_pooled<FOLD, T>(p, b, qt * (BM / FOLD), wave, lane);
     else publish_lists<FOLD, T>(p, b, qt * (BM / FOLD), s, wave, lane);
 #ifdef HVS_KERNEL_HOOKS
     if ((p.dbg & 512) && lane == 0) atomicAdd(&p.prof[5], clock64() - c_pub);
@@ -1087,7 +1087,10 @@ __global__ __launch_bounds__(T::GT, T::GT == 512 ? 2 : 1) void mfma_stream_kerne
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the block
     __syncthreads();
-    if (!DISTCOL) publish_lists<FOLD, T>(p, b, 0, s, wave, lane);
+    if (!DISTCOL) {
+        if (p.pooled_count) publish_pooled<FOLD, T>(p, b, 0, wave, lane);
+        else publish_lists<FOLD, T>(p, b, 0, s, wave, lane);
+    }
 #endif
 }
 
@@ -1162,7 +1165,7 @@ static int padded_fold(int fold) { return fold <= 1 ? 1 : (fold == 2 ? 2 : 4); }
 bool hvs_mfma_supported(hvs_index *idx, int nq, int fold, int k) {
     (void)nq;
     (void)idx;
-    return fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_MAX_K;
+    return fold >= 1 && fold <= 4 && k >= 1 && k <= MFMA_WIDE_K;
 }
 
 // A operand: groups of `pf` rows per output query (the last embedding repeated when fold < pf), in the
@@ -1479,7 +1482,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t xc_bytes = 0;
         const size_t xv_bytes = xchg ? up((size_t)nq * xm * 4) + up((size_t)nq * 4) : 0;
-        const size_t pc_bytes = xchg ? up((size_t)nq * 4) : 0;  // pooled-list counters, zeroed with the arrival counters
+        const bool pooled = xchg || k > MFMA_MAX_K;  // one list per query that every block appends to, ranked by select_pooled_kernel
+        const size_t pc_bytes = pooled ? up((size_t)nq * 4) : 0;  // its counters, zeroed with the overflow flag
         const size_t keys_b = up((size_t)nq * P2 * k * 8);
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
         HVS_TRY(hvs_ws_get(idx, 2, keys_b + up(64 + ls_bytes) + xc_bytes + pc_bytes + xv_bytes, &bufB));
@@ -1490,7 +1494,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         if (xchg) HVS_HIP(hipMemsetAsync(xc + xc_bytes + pc_bytes, 0xFF, xv_bytes, idx->stream));
         pp.prof = (unsigned long long *)(overflow + 4);
         pp.lockstep = lockstep ? (unsigned int *)(overflow + 16) : nullptr;
-        pp.pooled_count = xchg ? (unsigned int *)(xc + xc_bytes) : nullptr;
+        pp.pooled_count = pooled ? (unsigned int *)(xc + xc_bytes) : nullptr;
         pp.xchg_min = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes) : nullptr;
         pp.xchg_tau = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes + up((size_t)nq * xm * 4)) : nullptr;
         pp.cand = (uint64_t *)cand;
@@ -1517,12 +1521,13 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         else HVS_TRY((launch_search<HVS_BF16, Tile256>(pf, grid, idx->stream, pp)));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MFMA_SEARCH));
         HVS_TRY(hvs_prof_begin(idx));
-        if (xchg) {
+        if (pooled) {
             const int64_t *id_map = (hi_only || idx->emit_positions) ? nullptr : idx->ids;
             const size_t slots_q = (size_t)S * k;
-            if (k <= 64) select_pooled_kernel<1><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
-            else if (k <= 128) select_pooled_kernel<2><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
-            else select_pooled_kernel<MFMA_MAX_K / 64><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            if (k <= 64) select_pooled_kernel<1, CAND_MAX><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            else if (k <= 128) select_pooled_kernel<2, CAND_MAX><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            else if (k <= 256) select_pooled_kernel<4, CAND_MAX><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
+            else select_pooled_kernel<16, 2 * CAND_MAX><<<nq, 64, 0, idx->stream>>>((uint64_t *)bufA, pp.pooled_count, slots_q, k, id_map, o_dist, o_ids, o_count);
             HVS_HIP(hipGetLastError());
         } else
             HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, o_dist, o_ids, o_count, hi_only));

@@ -9,7 +9,9 @@
 #define KB 128        // bytes of one tile row per k-step
 #define CAND_MAX 1024   // capacity of a candidate array (entries) for k > 128: 16 keys per lane when a wave holds one in registers
 #define CAND_SMALL 512  // ... for k <= 128: 8 keys per lane
-#define MFMA_MAX_K 256
+#define MFMA_MAX_K 256   // largest k whose per-block lists are sorted inside the search kernels and merged list by list
+#define MFMA_WIDE_K 768  // largest k the batched kernels take: CAND_MAX less one 256-row tile of survivors; above MFMA_MAX_K the
+                         // blocks append their best k, unsorted, to one list per query that select_pooled_kernel ranks
 
 // Block-tile shapes.  BM x BN outputs per block, WM x WN waves, each wave (BM / WM) x (BN / WN) as
 // MT x NT MFMA tiles of 32 x 32.

@@ -46,7 +46,7 @@ enum { HVS_F32 = 0, HVS_F16 = 1, HVS_BF16 = 2 };
  * query are scored again from the fp32 rows in fp32, a query whose k-th exact score does not clear the bound of the
  * rows left out goes through the filter once more with 256 candidates, and what that leaves unproven is searched
  * again in full -- the exact top-k either way.  MFMA_SPLIT: the three products for every score, no filter.
- * MFMA_F32: the fp32 MFMA kernel, no copy.  The matrix-pipe routes take k <= 256 (larger k: SCAN).
+ * MFMA_F32: the fp32 MFMA kernel, no copy.  The matrix-pipe routes take k <= 768 (larger k: SCAN, one pass per query).
  * AUTO picks by batch size.
  */
 enum { HVS_ALGO_AUTO = 0, HVS_ALGO_SCAN = 1, HVS_ALGO_MFMA = 2, HVS_ALGO_MFMA_F32 = 3, HVS_ALGO_MFMA_SPLIT = 4 };
