@@ -59,6 +59,12 @@ struct SearchParams {
     int xchg_w;               // values a block publishes per query: one per wave column of its tile (T::WN), or 1 (their minimum)
                               // where S * WN would pass the 1024 values one wave ranks
     uint32_t *xchg_tau;       // [nq_out] float bits of the bound derived from them; all ones (a NaN) before the launch
+    // later rounds of the exchange (exchange_candidates): at tile XCHG_TILE_2 and XCHG_TILE_3 of a block's stream every block
+    // publishes its xchg_r smallest candidate distances per query; round j = 1, 2 uses xchg_min2 / xchg_tau2 + (j - 1) * stride
+    uint32_t *xchg_min2;      // [2][1024][nq_out], all ones before the launch
+    uint32_t *xchg_tau2;      // [2][nq_out]
+    int xchg_r;               // values per block, query and later round (a power of two, S * xchg_r <= 1024)
+    int xchg_rounds;          // 1: the first tile only; 2, 3: the later rounds too
     unsigned int *pooled_count;  // optional (kernels built with XCHG): [nq_out] keys in a query's pooled list, zeroed before the launch;
                                  // `partial` then holds one list of S * k slots per query that every block appends its survivors to
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
@@ -577,6 +583,94 @@ __device__ __forceinline__ void exchange_bound(const SearchParams &p, const Bloc
     __syncthreads();
 }
 
+// Later rounds.  The bound of the first round sits near the k / (S x BN) quantile, and a block that sees a few hundred
+// tiles never collects the 2 k candidates a ranking of its own needs, so tau stays there for the whole stream (cfg5 shard,
+// 256 queries, k = 100: 0.15 % of the scores survive the tile tests from the first tile to the last, 12 survivor groups
+// per wave and tile, 25 % of the launch in epilogues).  But between them the blocks hold, in their candidate arrays, every
+// row below that bound seen so far: after t tiles the global k-th smallest of those is the k-th distance over S x BN x t
+// rows.  So at tile XCHG_TILE_2 (and XCHG_TILE_3) every block publishes its r smallest candidate distances per query -- a
+// lane per query walks its array, which holds a handful of keys -- and the k-th smallest of the S x r published values
+// (distinct rows, so an upper bound whatever r is; equal to the exact value unless one block holds more than r of the k
+// best) becomes the new bound, found and handed out as in the first round.
+#define XCHG_TILE_2 8
+#define XCHG_TILE_3 64
+template <int FOLD, class T, int R>
+__device__ __forceinline__ void exchange_candidates_r(const SearchParams &p, const BlockState &b, int round, int s, int64_t a_row0, int lane,
+                                                      int wave, int tid) {
+    constexpr int BMQ = T::BM / FOLD;
+    const int M = p.S * R;
+    const int64_t q0 = a_row0 / FOLD;
+    uint32_t *mins = p.xchg_min2 + (size_t)(round - 1) * 1024 * p.nq_out;
+    uint32_t *taus = p.xchg_tau2 + (size_t)(round - 1) * p.nq_out;
+    __syncthreads();  // the arrays as the tile's epilogue and rankings left them
+    for (int base = wave * 64; base < BMQ; base += T::NW * 64) {
+        const int ql = base + lane;
+        const int64_t qo = q0 + ql;
+        if (ql >= BMQ || qo >= p.nq_out) continue;
+        int c = b.cnt[ql];
+        c = c > p.cap ? p.cap : c;
+        const uint64_t *arr = b.my_cand + (size_t)ql * p.cap;
+        uint32_t best[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) best[i] = 0xFF800000u;  // the image of +inf: published, but no row
+        for (int j = 0; j < c; j++) {
+            uint32_t v = (uint32_t)(arr[j] >> 32);
+#pragma unroll
+            for (int i = 0; i < R; i++) {  // keeps best[] ascending
+                const uint32_t lo = v < best[i] ? v : best[i];
+                v = v < best[i] ? best[i] : v;
+                best[i] = lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++)
+            __hip_atomic_store(mins + (size_t)(s * R + i) * p.nq_out + qo, best[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int ql = s + wave * p.S; ql < BMQ; ql += T::NW * p.S) {
+        const int64_t qo = q0 + ql;
+        if (qo >= p.nq_out) break;
+        const uint32_t *vals = mins + qo;
+        uint32_t t;
+        if (M <= 64) t = xchg_kth<1>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 128) t = xchg_kth<2>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 256) t = xchg_kth<4>(vals, p.nq_out, M, p.k, lane);
+        else if (M <= 512) t = xchg_kth<8>(vals, p.nq_out, M, p.k, lane);
+        else t = xchg_kth<16>(vals, p.nq_out, M, p.k, lane);
+        if (lane == 0) {
+            float bound = __builtin_nanf("");
+            if (t < hvs_ord(INFINITY)) {
+                const float d = hvs_unord(t);
+                bound = d == 0.0f ? 1.4e-45f : (d > 0.0f ? __uint_as_float(__float_as_uint(d) + 1u) : __uint_as_float(__float_as_uint(d) - 1u));
+            }
+            __hip_atomic_store(taus + qo, __float_as_uint(bound), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int i = tid; i < BMQ; i += T::GT) {
+        if (q0 + i >= p.nq_out) continue;
+        uint32_t bits = 0xFFFFFFFFu;
+        for (int spin = 0; spin < XCHG_SPINS; spin++) {
+            bits = __hip_atomic_load(taus + q0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits != 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const float t = __uint_as_float(bits);
+        if (t < b.tau[i]) b.tau[i] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < T::BM; i += T::GT)
+        if (a_row0 + i < p.nA && b.tau[i / FOLD] < p.thr) b.bound[i] = prefilter_bound(b.tau[i / FOLD], b.qinv[i]);
+    __syncthreads();
+}
+template <int FOLD, class T>
+__device__ __forceinline__ void exchange_candidates(const SearchParams &p, const BlockState &b, int round, int s, int64_t a_row0, int lane,
+                                                    int wave, int tid) {
+    if (p.xchg_r >= 16) exchange_candidates_r<FOLD, T, 16>(p, b, round, s, a_row0, lane, wave, tid);
+    else if (p.xchg_r >= 8) exchange_candidates_r<FOLD, T, 8>(p, b, round, s, a_row0, lane, wave, tid);
+    else if (p.xchg_r >= 4) exchange_candidates_r<FOLD, T, 4>(p, b, round, s, a_row0, lane, wave, tid);
+    else if (p.xchg_r >= 2) exchange_candidates_r<FOLD, T, 2>(p, b, round, s, a_row0, lane, wave, tid);
+    else exchange_candidates_r<FOLD, T, 1>(p, b, round, s, a_row0, lane, wave, tid);
+}
+
 // The other half of a short-stream launch: with a bound from the pooled first tiles a block ends up with a handful of
 // survivors per query, and sorting and merging S lists of k slots each per query costs more than the contraction (256
 // queries x 195 k rows, k = 100: 65 us of sorting inside the kernel and three merge launches, against 80 us of K loops).
@@ -786,6 +880,11 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         if (prof) c3 = clock64();
 #endif
         compact_lists<FOLD, T>(p, b, wave, lane);
+        if (XCHG && p.xchg_rounds > 1) {
+            const int64_t done = tile - tile_lo + 1;
+            if (done == XCHG_TILE_2 || (done == XCHG_TILE_3 && p.xchg_rounds > 2))
+                exchange_candidates<FOLD, T>(p, b, done == XCHG_TILE_2 ? 1 : 2, s, a_row0, lane, wave, tid);
+        }
 #ifdef HVS_KERNEL_HOOKS
         if (prof) {
             const unsigned long long c4 = clock64();
@@ -1481,7 +1580,15 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         const bool xchg = want_xchg && tau0 == nullptr && (pp.dbg & ~512) == 0 && xchg_fits(S);
         auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t xc_bytes = 0;
-        const size_t xv_bytes = xchg ? up((size_t)nq * xm * 4) + up((size_t)nq * 4) : 0;
+        // later rounds: when every block still has at least as many tiles ahead of it as behind it at that point
+        const int64_t tiles_per_block = pp.T / S;
+        int rounds = 1;
+        if (xchg && !getenv("HVS_XCHG_ONE_ROUND")) rounds += (tiles_per_block >= 2 * XCHG_TILE_2 ? 1 : 0) + (tiles_per_block >= 2 * XCHG_TILE_3 ? 1 : 0);
+        int xr = 1;
+        while (xr < 16 && S * xr * 2 <= 1024) xr *= 2;
+        const size_t x1_bytes = up((size_t)nq * xm * 4) + up((size_t)nq * 4);
+        const size_t x2_bytes = rounds > 1 ? up((size_t)2 * 1024 * nq * 4) + up((size_t)2 * nq * 4) : 0;
+        const size_t xv_bytes = xchg ? x1_bytes + x2_bytes : 0;
         const bool pooled = xchg || k > MFMA_MAX_K;  // one list per query that every block appends to, ranked by select_pooled_kernel
         const size_t pc_bytes = pooled ? up((size_t)nq * 4) : 0;  // its counters, zeroed with the overflow flag
         const size_t keys_b = up((size_t)nq * P2 * k * 8);
@@ -1497,6 +1604,10 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         pp.pooled_count = pooled ? (unsigned int *)(xc + xc_bytes) : nullptr;
         pp.xchg_min = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes) : nullptr;
         pp.xchg_tau = xchg ? (uint32_t *)(xc + xc_bytes + pc_bytes + up((size_t)nq * xm * 4)) : nullptr;
+        pp.xchg_rounds = xchg ? rounds : 0;
+        pp.xchg_r = xr;
+        pp.xchg_min2 = (xchg && rounds > 1) ? (uint32_t *)(xc + xc_bytes + pc_bytes + x1_bytes) : nullptr;
+        pp.xchg_tau2 = (xchg && rounds > 1) ? (uint32_t *)(xc + xc_bytes + pc_bytes + x1_bytes + up((size_t)2 * 1024 * nq * 4)) : nullptr;
         pp.cand = (uint64_t *)cand;
         pp.partial = (uint64_t *)bufA;
         pp.overflow = overflow;
