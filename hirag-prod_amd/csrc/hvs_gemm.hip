@@ -65,6 +65,7 @@ struct SearchParams {
     uint32_t *xchg_tau2;      // [2][nq_out]
     int xchg_r;               // values per block, query and later round (a power of two, S * xchg_r <= 1024)
     int xchg_rounds;          // 1: the first tile only; 2, 3: the later rounds too
+    int xchg_t2, xchg_t3;     // the tiles (counted from 1 in a block's stream) after which the later rounds run
     unsigned int *pooled_count;  // optional (kernels built with XCHG): [nq_out] keys in a query's pooled list, zeroed before the launch;
                                  // `partial` then holds one list of S * k slots per query that every block appends its survivors to
     int dbg;        // timing experiments only (env HVS_DBG; results are wrong with 4 or 8): 4 no k-step barrier, 8 no epilogue,
@@ -882,8 +883,8 @@ __global__ __launch_bounds__(T::GT, T::GT <= 256 ? 2 : 1) void mfma_search_kerne
         compact_lists<FOLD, T>(p, b, wave, lane);
         if (XCHG && p.xchg_rounds > 1) {
             const int64_t done = tile - tile_lo + 1;
-            if (done == XCHG_TILE_2 || (done == XCHG_TILE_3 && p.xchg_rounds > 2))
-                exchange_candidates<FOLD, T>(p, b, done == XCHG_TILE_2 ? 1 : 2, s, a_row0, lane, wave, tid);
+            if (done == p.xchg_t2 || (done == p.xchg_t3 && p.xchg_rounds > 2))
+                exchange_candidates<FOLD, T>(p, b, done == p.xchg_t2 ? 1 : 2, s, a_row0, lane, wave, tid);
         }
 #ifdef HVS_KERNEL_HOOKS
         if (prof) {
@@ -1583,7 +1584,12 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         // later rounds: when every block still has at least as many tiles ahead of it as behind it at that point
         const int64_t tiles_per_block = pp.T / S;
         int rounds = 1;
-        if (xchg && !getenv("HVS_XCHG_ONE_ROUND")) rounds += (tiles_per_block >= 2 * XCHG_TILE_2 ? 1 : 0) + (tiles_per_block >= 2 * XCHG_TILE_3 ? 1 : 0);
+        int t2 = XCHG_TILE_2, t3 = XCHG_TILE_3;
+        if (const char *e = getenv("HVS_XCHG_T2")) t2 = atoi(e) > 0 ? atoi(e) : t2;  // experiments
+        if (const char *e = getenv("HVS_XCHG_T3")) t3 = atoi(e) > t2 ? atoi(e) : t3;
+        if (xchg && !getenv("HVS_XCHG_ONE_ROUND")) rounds += (tiles_per_block >= 2 * t2 ? 1 : 0) + (tiles_per_block >= 2 * t2 && tiles_per_block >= 2 * t3 ? 1 : 0);
+        pp.xchg_t2 = t2;
+        pp.xchg_t3 = t3;
         int xr = 1;
         while (xr < 16 && S * xr * 2 <= 1024) xr *= 2;
         const size_t x1_bytes = up((size_t)nq * xm * 4) + up((size_t)nq * 4);

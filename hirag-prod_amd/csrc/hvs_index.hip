@@ -443,16 +443,16 @@ __global__ void gather_attrs_kernel(const int4 *__restrict__ src, const uint32_t
 // One wave per 64 consecutive rows and step: lane i tests row base + i (one coalesced 16-byte load per lane), a ballot
 // makes the two mask words.  The uri codes sit sorted in LDS; membership is a binary search.
 #define FILTER_URIS_LDS 8192
-__global__ __launch_bounds__(256) void filter_mask_kernel(const int4 *__restrict__ attrs, int64_t n, int32_t ws, int32_t kb, int32_t access,
-                                                           const int32_t *__restrict__ uris, int n_uris, uint32_t *__restrict__ mask) {
+__global__ __launch_bounds__(256) void filter_mask_kernel(const int4 *__restrict__ attrs, int64_t n, int64_t first_step, int64_t last_step, int32_t ws,
+                                                           int32_t kb, int32_t access, const int32_t *__restrict__ uris, int n_uris,
+                                                           uint32_t *__restrict__ mask) {
     __shared__ int32_t s_uris[FILTER_URIS_LDS];
     for (int i = threadIdx.x; i < n_uris; i += blockDim.x) s_uris[i] = uris[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t n_steps = (n + 63) / 64;
-    for (int64_t step = wave; step < n_steps; step += n_waves) {
+    for (int64_t step = first_step + wave; step < last_step; step += n_waves) {  // 64 rows per step
         const int64_t row = step * 64 + lane;
         bool ok = row < n;
         if (ok) {
@@ -485,7 +485,7 @@ int hvs_attrs_ensure(hvs_index *idx) {
     return 0;
 }
 
-int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask) {
+int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask, int64_t row_begin, int64_t row_end) {
     *d_mask = nullptr;
     HVS_REQUIRE(f->n_uris >= 0 && f->n_uris <= HVS_MAX_FILTER_URIS, "hvs_filter: %d uri codes, at most %d", f->n_uris, HVS_MAX_FILTER_URIS);
     HVS_REQUIRE(f->n_uris == 0 || f->uris != nullptr, "hvs_filter: n_uris = %d with a NULL list", f->n_uris);
@@ -496,6 +496,8 @@ int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask
     HVS_TRY(hvs_attrs_ensure(idx));
     const size_t words = (size_t)((idx->n + 31) / 32);
     void *m = nullptr, *u = nullptr;
+    const int32_t *d_uris = nullptr;
+    int n_uris = 0;
     HVS_TRY(hvs_ws_get(idx, 8, words * 4 + 8, &m));
     if (has_uris) {
         // WHERE uri IN (): an empty list matches nothing -- one code no row can carry keeps the kernel's path uniform
@@ -505,11 +507,26 @@ int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask
         HVS_TRY(hvs_ws_get(idx, 9, sorted.size() * 4, &u));
         HVS_HIP(hipMemcpyAsync(u, sorted.data(), sorted.size() * 4, hipMemcpyHostToDevice, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));  // `sorted` is pageable host memory about to go out of scope
-        filter_mask_kernel<<<grid_for((idx->n + 63) / 64 * 64, 256, 2048), 256, 0, idx->stream>>>(
-            idx->attrs, idx->n, f->workspace, f->knowledge_base, f->access, (const int32_t *)u, (int)sorted.size(), (uint32_t *)m);
-    } else {
-        filter_mask_kernel<<<grid_for((idx->n + 63) / 64 * 64, 256, 2048), 256, 0, idx->stream>>>(
-            idx->attrs, idx->n, f->workspace, f->knowledge_base, f->access, nullptr, 0, (uint32_t *)m);
+        d_uris = (const int32_t *)u;
+        n_uris = (int)sorted.size();
+    }
+    // the rows a search can reach: [row_begin, row_end), and on a table in group order with a group clause only that
+    // group's range and the rows added since -- the words of the mask that cover other rows are left as they are
+    if (row_end < 0 || row_end > idx->n) row_end = idx->n;
+    if (row_begin < 0) row_begin = 0;
+    int64_t spans[2][2] = {{row_begin, row_end}, {0, 0}};
+    int64_t gb = 0, ge = 0;
+    if (f->group >= 0 && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, f->group, &gb, &ge)) {
+        spans[0][0] = row_begin > gb ? row_begin : gb;
+        spans[0][1] = row_end < ge ? row_end : ge;
+        spans[1][0] = row_begin > idx->part_n ? row_begin : idx->part_n;
+        spans[1][1] = row_end;
+    }
+    for (int i = 0; i < 2; i++) {
+        if (spans[i][0] >= spans[i][1]) continue;
+        const int64_t first_step = spans[i][0] / 64, last_step = (spans[i][1] + 63) / 64;
+        filter_mask_kernel<<<grid_for((last_step - first_step) * 64, 256, 2048), 256, 0, idx->stream>>>(
+            idx->attrs, idx->n, first_step, last_step, f->workspace, f->knowledge_base, f->access, d_uris, n_uris, (uint32_t *)m);
     }
     HVS_HIP(hipGetLastError());
     *d_mask = (const uint32_t *)m;

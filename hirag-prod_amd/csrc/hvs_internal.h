@@ -137,9 +137,10 @@ int hvs_range_collect(hvs_index *idx, const hvs_live_params &lp, int64_t capacit
 int hvs_merge_launch(hipStream_t st, const float *in_dist, const int64_t *in_ids, const int32_t *in_count, int nq, int P, int k,
                      int64_t dist_q, int64_t dist_p, int64_t ids_q, int64_t ids_p, int64_t cnt_q, int64_t cnt_p, float *out_dist,
                      int64_t *out_ids, int32_t *out_count);  // hvs_scan.hip
-// Row bitmask of a filter's attribute clauses over rows [0, n) into workspace 8 (*d_mask = nullptr when the filter has
-// none; the group clause stays with the kernels' own group test).  hvs_index.hip
-int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask);
+// Row bitmask of a filter's attribute clauses into workspace 8, for the rows a search of [row_begin, row_end) with that
+// filter can reach (*d_mask = nullptr when the filter has no such clause; the group clause stays with the kernels' own
+// group test, or with the group's row range on a table in group order).  hvs_index.hip
+int hvs_filter_mask(hvs_index *idx, const hvs_filter *f, const uint32_t **d_mask, int64_t row_begin, int64_t row_end);
 int hvs_attrs_ensure(hvs_index *idx);
 // hvs_search / hvs_range_search with a row mask that already lies on the device whatever on_device says (hvs_scan.hip)
 int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int k, int32_t group_filter, const uint32_t *row_mask,

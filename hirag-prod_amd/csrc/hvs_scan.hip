@@ -846,7 +846,7 @@ extern "C" int hvs_search_filtered(hvs_index *idx, const float *queries, int nq,
     const uint32_t *d_mask = nullptr;
     if (filter && nq > 0) {
         HVS_HIP(hipSetDevice(idx->device));
-        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask));
+        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask, row_begin, row_end));
     }
     return hvs_search_core(idx, queries, nq, fold, k, filter ? filter->group : -1, d_mask, true, max_distance, row_begin, row_end, out_dist,
                            out_ids, out_count, on_device, algo);
@@ -1216,7 +1216,7 @@ extern "C" int hvs_range_search_filtered(hvs_index *idx, const float *queries, i
     const uint32_t *d_mask = nullptr;
     if (filter) {
         HVS_HIP(hipSetDevice(idx->device));
-        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask));
+        HVS_TRY(hvs_filter_mask(idx, filter, &d_mask, row_begin, row_end));
     }
     return hvs_range_search_core(idx, queries, fold, filter ? filter->group : -1, d_mask, true, max_distance, row_begin, row_end, capacity,
                                  out_dist, out_ids, out_total, on_device);

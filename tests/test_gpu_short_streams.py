@@ -89,3 +89,26 @@ def test_long_pooled_lists_are_ranked_in_rounds(hvs):
         for i in range(4):
             parity.check_topk(dist[i], ids[i], cnt[i], parity.full_distances(rows, q[i], "f16"), k, label=f"k={k} q={i}")
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_blocks_in_lockstep_or_free_running_give_the_same_answers(hvs, dtype):
+    """the arrival counters that keep the blocks of a corpus stream on the same tile only change timing"""
+    rng = np.random.default_rng(12)
+    n, d, nq, k = 70_000, 96, 600, 10  # three query tiles of 256 (two of 128 for fp32 rows): several blocks per stream
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows)
+    algo = "mfma_f32" if dtype == "f32" else "mfma"
+    locked = idx.search(q, k=k, algo=algo)
+    os.environ["HVS_NO_LOCKSTEP"] = "1"
+    try:
+        free = idx.search(q, k=k, algo=algo)
+    finally:
+        del os.environ["HVS_NO_LOCKSTEP"]
+    for a, b in zip(locked, free):
+        assert np.array_equal(a, b)
+    for i in (0, 255, 256, nq - 1):
+        parity.check_topk(locked[0][i], locked[1][i], locked[2][i], parity.full_distances(rows, q[i], dtype), k, label=f"{dtype} lockstep q={i}")
+    idx.close()
