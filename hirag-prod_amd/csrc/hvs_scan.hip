@@ -10,6 +10,7 @@
 #include "hvs_internal.h"
 
 #include <mutex>
+#include <unordered_map>
 
 #define SCAN_THREADS 256
 #define SCAN_WAVES (SCAN_THREADS / 64)
@@ -671,15 +672,34 @@ int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int 
 template <int DT, int NQ, int LPR, bool DISTONLY>
 static int launch_scan_one(int64_t want_blocks, size_t lds, hipStream_t s, const ScanParams &p, int *grid_out, bool dry) {
     const void *fn = reinterpret_cast<const void *>(&scan_kernel<DT, NQ, LPR, DISTONLY>);
-    if (lds > 48 * 1024) HVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    HVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SCAN_THREADS, lds));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
-    int dev = 0, cus = 256;
+    // resident blocks of this kernel at this LDS size on this device: asked of the runtime once (four runtime calls per
+    // launch cost a single query on a small table more than its merges)
+    int dev = 0;
     HVS_HIP(hipGetDevice(&dev));
-    HVS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int64_t grid = (int64_t)per_cu * cus;
+    int64_t grid = 0;
+    {
+        static std::mutex mu;
+        static std::unordered_map<uint64_t, int> known;
+        static std::unordered_map<const void *, size_t> lds_allowed;  // a kernel's dynamic-LDS limit is only ever raised
+        const uint64_t key = ((uint64_t)(uintptr_t)fn * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)lds << 8) ^ (uint64_t)dev;
+        std::lock_guard<std::mutex> guard(mu);
+        auto it = known.find(key);
+        if (it == known.end()) {
+            size_t &allowed = lds_allowed[fn];
+            if (lds > 48 * 1024 && lds > allowed) {
+                HVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                allowed = lds;
+            }
+            int per_cu = 0, cus = 256;
+            HVS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, SCAN_THREADS, lds));
+            if (per_cu < 1) per_cu = 1;
+            if (per_cu > 4) per_cu = 4;
+            HVS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            it = known.emplace(key, per_cu * cus).first;
+        }
+        grid = it->second;
+    }
+    if (const char *e = getenv("HVS_SCAN_MAX_BLOCKS")) grid = atoll(e) > 0 && atoll(e) < grid ? atoll(e) : grid;  // experiments
     if (want_blocks < grid) grid = want_blocks < 1 ? 1 : want_blocks;
     *grid_out = (int)grid;
     if (dry) return 0;
