@@ -5,8 +5,8 @@
 // lanes per row, several rows in flight per wave); the query embeddings sit in LDS in the rows' own
 // element type; every wave keeps a sorted top-k list per query in LDS and only touches it when a row
 // beats the list's current worst (rare after the first few hundred rows), so the score vector is never
-// written anywhere.  Every wave then writes its k keys; log_32(P) tiny merge launches reduce the P wave
-// lists to the final answer.
+// written anywhere.  Every block then merges its waves' lists in LDS and writes k keys; log_32(P) tiny merge
+// launches reduce the P block lists to the final answer.
 #include "hvs_internal.h"
 
 #include <mutex>
@@ -37,7 +37,7 @@ struct ScanParams {
     int k;
     uint32_t thr_ord;  // ordered-uint image of the strict distance bound
     int32_t group_filter;
-    uint64_t *partial;  // [nq_out, gridDim.x * SCAN_WAVES, k] keys (topk mode)
+    uint64_t *partial;  // [nq_out, gridDim.x, k] keys (topk mode)
     float *dist_out;    // [row_end - row_begin] (distance mode)
 };
 
@@ -207,6 +207,150 @@ template <int V, int W, int STRIDE = 1> __device__ __forceinline__ void reduce_s
 }
 constexpr int hvs_pow2_ceil(int v) { return v <= 1 ? 1 : 2 * hvs_pow2_ceil((v + 1) / 2); }
 constexpr int hvs_log2(int v) { return v <= 1 ? 0 : 1 + hvs_log2(v / 2); }
+
+// ---- list merging -------------------------------------------------------------------------------
+// A wave holds one ascending list of N = 64 * KL keys in registers, slot i = e * 64 + lane in a[e].
+// Merging another ascending list B keeps the N smallest of the union: c[i] = min(a[i], B[N-1-i]) is a
+// bitonic sequence holding exactly those keys, and log2(N) compare-exchange rounds sort it (rounds with
+// stride >= 64 pair registers of one lane, rounds with stride < 64 pair lanes through a shuffle).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
+    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <int KL>
+__device__ __forceinline__ void wl_load(uint64_t (&a)[KL], const uint64_t *src, int n, int lane) {
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        a[e] = i < n ? src[i] : HVS_KEY_EMPTY;
+    }
+}
+
+// the other list, reversed, as the merge below consumes it
+template <int KL>
+__device__ __forceinline__ void wl_load_reversed(uint64_t (&b)[KL], const uint64_t *other, int n, int lane) {
+    constexpr int N = 64 * KL;
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = N - 1 - (e * 64 + lane);
+        b[e] = i < n ? other[i] : HVS_KEY_EMPTY;
+    }
+}
+
+// a = the 64 KL smallest of a (ascending) and b (a list loaded by wl_load_reversed), ascending
+template <int KL>
+__device__ __forceinline__ void wl_merge(uint64_t (&a)[KL], const uint64_t (&b)[KL], int lane) {
+#pragma unroll
+    for (int e = 0; e < KL; e++) a[e] = b[e] < a[e] ? b[e] : a[e];
+#pragma unroll
+    for (int se = KL / 2; se >= 1; se >>= 1) {  // strides 64 * se: register pairs inside a lane
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            if ((e & se) == 0) {
+                const uint64_t lo = a[e] < a[e + se] ? a[e] : a[e + se];
+                const uint64_t hi = a[e] < a[e + se] ? a[e + se] : a[e];
+                a[e] = lo;
+                a[e + se] = hi;
+            }
+        }
+    }
+#pragma unroll
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+        const bool keep_min = (lane & stride) == 0;
+#pragma unroll
+        for (int e = 0; e < KL; e++) {
+            const uint64_t o = shfl_xor_u64(a[e], stride);
+            const uint64_t lo = a[e] < o ? a[e] : o;
+            const uint64_t hi = a[e] < o ? o : a[e];
+            a[e] = keep_min ? lo : hi;
+        }
+    }
+}
+
+#define MERGE_WAVES 4
+#define MERGE_BLOCK_FAN (MERGE_WAVES * MERGE_FAN)
+
+// A block of MERGE_WAVES waves merges nl <= MERGE_BLOCK_FAN consecutive ascending lists of k keys: wave w lists
+// [w MERGE_FAN, (w + 1) MERGE_FAN) one after the other, then the first wave the four results, handed over in LDS
+// (handed: (MERGE_WAVES - 1) x 64 KL keys).  The result is in the first wave's a[].  All threads of the block call it.
+template <int KL>
+__device__ __forceinline__ void block_merge(uint64_t (&a)[KL], const uint64_t *lists, int nl_block, int k, uint64_t *handed, int wave, int lane) {
+    constexpr int N = 64 * KL;
+    const int first = wave * MERGE_FAN;
+    const int nl = nl_block - first < MERGE_FAN ? (nl_block - first > 0 ? nl_block - first : 0) : MERGE_FAN;
+    const uint64_t *src = lists + (size_t)first * k;
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        a[e] = (nl > 0 && i < k) ? src[i] : HVS_KEY_EMPTY;
+    }
+    // the lists' addresses do not depend on the merges: fetch them a group ahead, so that a wave waits for global
+    // memory once per group instead of once per list
+    constexpr int AHEAD = KL <= 2 ? 8 : (KL <= 4 ? 4 : 2);
+    for (int j0 = 1; j0 < nl; j0 += AHEAD) {
+        uint64_t b[AHEAD][KL];
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
+            const uint64_t *other = src + (size_t)(j0 + u < nl ? j0 + u : j0) * k;
+#pragma unroll
+            for (int e = 0; e < KL; e++) {
+                const int i = N - 1 - (e * 64 + lane);  // reversed, as wl_merge consumes it
+                b[u][e] = (j0 + u < nl && i < k) ? other[i] : HVS_KEY_EMPTY;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++)
+            if (j0 + u < nl) wl_merge<KL>(a, b[u], lane);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < KL; e++) handed[(wave - 1) * N + e * 64 + lane] = a[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < MERGE_WAVES; w++) {
+        if (w * MERGE_FAN >= nl_block) break;  // that wave had no list
+        uint64_t b[KL];
+        wl_load_reversed<KL>(b, handed + (w - 1) * N, N, lane);
+        wl_merge<KL>(a, b, lane);
+    }
+}
+
+template <int KL> __device__ __forceinline__ void merged_to_keys(const uint64_t (&a)[KL], uint64_t *o, int k, int lane) {
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        if (i < k) o[i] = a[e];
+    }
+}
+
+// the final list as distances, ids (ids == nullptr: row positions) and the count of one query
+template <int KL>
+__device__ __forceinline__ void merged_to_results(const uint64_t (&a)[KL], int k, const int64_t *ids, float *out_dist, int64_t *out_ids,
+                                                  int32_t *out_count, int lane) {
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        const int i = e * 64 + lane;
+        const bool have = i < k && a[e] != HVS_KEY_EMPTY;
+        cnt += __popcll(__ballot(have));
+        if (i < k) {
+            float d = __builtin_inff();
+            int64_t id = -1;
+            if (have) {
+                d = hvs_unord((uint32_t)(a[e] >> 32));
+                const uint32_t row = (uint32_t)a[e];
+                id = ids ? ids[row] : (int64_t)row;
+            }
+            out_dist[i] = d;
+            out_ids[i] = id;
+        }
+    }
+    if (lane == 0) *out_count = cnt;
+}
 
 // ---- the scan -----------------------------------------------------------------------------------
 // LPR = lanes per row: 64 (one row per wave pass) or 32 (two rows per pass, for rows of <= 2 KB, which
@@ -467,148 +611,86 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
     }
     if (DISTONLY) return;
 
-    // publish: every wave writes its k keys per query (ascending, padded); the merge kernels do the rest
-    const int64_t n_lists = (int64_t)gridDim.x * SCAN_WAVES;
+    // publish: one ascending list of k keys per block and query (padded); the merge kernels do the rest.  The block's
+    // four wave lists are merged where they lie, in LDS: a key's place in the union is its index in its own list plus
+    // the number of keys before it in each of the others (keys carry the row number, so no two are equal).
+    int *counts = reinterpret_cast<int *>(row_queue + wave * (64 * RG));  // the wave's own queue is free now
+    if (lane < NQ) {
+        int c = 0;
 #pragma unroll
-    for (int qo = 0; qo < NQ; qo++) {
-        if (qo >= p.nq_out) break;
-        wave_fence();
-        const volatile uint64_t *L = myL + (size_t)qo * p.k;
-        uint64_t *out = p.partial + ((size_t)qo * n_lists + gwave) * p.k;
-        for (int i = lane; i < p.k; i += 64) out[i] = i < cnt[qo] ? L[i] : HVS_KEY_EMPTY;
+        for (int qo = 0; qo < NQ; qo++) c = lane == qo ? cnt[qo] : c;
+        counts[lane] = c;
     }
-}
-
-// ---- list merging -------------------------------------------------------------------------------
-// A wave holds one ascending list of N = 64 * KL keys in registers, slot i = e * 64 + lane in a[e].
-// Merging another ascending list B keeps the N smallest of the union: c[i] = min(a[i], B[N-1-i]) is a
-// bitonic sequence holding exactly those keys, and log2(N) compare-exchange rounds sort it (rounds with
-// stride >= 64 pair registers of one lane, rounds with stride < 64 pair lanes through a shuffle).
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, mask);
-    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), mask);
-    return ((uint64_t)hi << 32) | lo;
-}
-
-template <int KL>
-__device__ __forceinline__ void wl_load(uint64_t (&a)[KL], const uint64_t *src, int n, int lane) {
+    __syncthreads();
+    for (int qo = 0; qo < p.nq_out; qo++) {
+        uint64_t *out = p.partial + ((size_t)qo * gridDim.x + blockIdx.x) * p.k;
+        int cw[SCAN_WAVES], total = 0;
 #pragma unroll
-    for (int e = 0; e < KL; e++) {
-        const int i = e * 64 + lane;
-        a[e] = i < n ? src[i] : HVS_KEY_EMPTY;
-    }
-}
-
-// the other list, reversed, as the merge below consumes it
-template <int KL>
-__device__ __forceinline__ void wl_load_reversed(uint64_t (&b)[KL], const uint64_t *other, int n, int lane) {
-    constexpr int N = 64 * KL;
+        for (int w = 0; w < SCAN_WAVES; w++) {
+            cw[w] = reinterpret_cast<const int *>(row_queue + w * (64 * RG))[qo];
+            total += cw[w];
+        }
 #pragma unroll
-    for (int e = 0; e < KL; e++) {
-        const int i = N - 1 - (e * 64 + lane);
-        b[e] = i < n ? other[i] : HVS_KEY_EMPTY;
-    }
-}
-
-// a = the 64 KL smallest of a (ascending) and b (a list loaded by wl_load_reversed), ascending
-template <int KL>
-__device__ __forceinline__ void wl_merge(uint64_t (&a)[KL], const uint64_t (&b)[KL], int lane) {
+        for (int w = 0; w < SCAN_WAVES; w++) {
+            const uint64_t *mine = lists + ((size_t)w * p.nq_out + qo) * p.k;
+            for (int i = tid; i < cw[w]; i += SCAN_THREADS) {
+                const uint64_t key = mine[i];
+                int rank = i;
 #pragma unroll
-    for (int e = 0; e < KL; e++) a[e] = b[e] < a[e] ? b[e] : a[e];
-#pragma unroll
-    for (int se = KL / 2; se >= 1; se >>= 1) {  // strides 64 * se: register pairs inside a lane
-#pragma unroll
-        for (int e = 0; e < KL; e++) {
-            if ((e & se) == 0) {
-                const uint64_t lo = a[e] < a[e + se] ? a[e] : a[e + se];
-                const uint64_t hi = a[e] < a[e + se] ? a[e + se] : a[e];
-                a[e] = lo;
-                a[e + se] = hi;
+                for (int o = 0; o < SCAN_WAVES; o++) {
+                    if (o == w) continue;
+                    const uint64_t *other = lists + ((size_t)o * p.nq_out + qo) * p.k;
+                    int lo = 0, hi = cw[o];
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (other[mid] < key) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    rank += lo;
+                }
+                if (rank < p.k) out[rank] = key;
             }
         }
-    }
-#pragma unroll
-    for (int stride = 32; stride >= 1; stride >>= 1) {
-        const bool keep_min = (lane & stride) == 0;
-#pragma unroll
-        for (int e = 0; e < KL; e++) {
-            const uint64_t o = shfl_xor_u64(a[e], stride);
-            const uint64_t lo = a[e] < o ? a[e] : o;
-            const uint64_t hi = a[e] < o ? o : a[e];
-            a[e] = keep_min ? lo : hi;
-        }
+        for (int i = total + tid; i < p.k; i += SCAN_THREADS) out[i] = HVS_KEY_EMPTY;
     }
 }
 
-// in: [nq, P, k] ascending keys padded with HVS_KEY_EMPTY.  One wave merges MERGE_FAN consecutive lists.
+// ---- list merging: the kernel ------------------------------------------------------------------
+// in: [nq, P, k] ascending keys padded with HVS_KEY_EMPTY.  One block merges MERGE_BLOCK_FAN consecutive lists: each of
+// its four waves MERGE_FAN of them, one after the other, then the first wave the four results, handed over in LDS.
+// A level costs a launch and a round trip to memory whatever it merges, so the levels are few and wide: the 1024
+// block lists of a scan take two launches.
 // FINAL = false: out keys [nq, P2, k].  FINAL = true (P2 == 1): distances / ids / counts.
 template <int KL, bool FINAL>
-__global__ __launch_bounds__(64) void merge_lists_kernel(const uint64_t *__restrict__ in, int P, int k, uint64_t *out_keys,
-                                                          const int64_t *__restrict__ ids, float *out_dist,
-                                                          int64_t *out_ids, int32_t *out_count) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * MERGE_WAVES) void merge_lists_kernel(const uint64_t *__restrict__ in, int P, int k, uint64_t *out_keys,
+                                                                        const int64_t *__restrict__ ids, float *out_dist,
+                                                                        int64_t *out_ids, int32_t *out_count) {
+    __shared__ uint64_t handed[(MERGE_WAVES - 1) * 64 * KL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = blockIdx.x;
     const int q = blockIdx.y;
     const int P2 = gridDim.x;
-    const int first = grp * MERGE_FAN;
-    const int nl = (P - first) < MERGE_FAN ? (P - first) : MERGE_FAN;
-    const uint64_t *src = in + ((size_t)q * P + first) * k;
+    const int first = grp * MERGE_BLOCK_FAN;
     uint64_t a[KL];
-    wl_load<KL>(a, src, k, lane);
-    // the lists' addresses do not depend on the merges: fetch them a group ahead, so that a wave waits for global
-    // memory once per group instead of once per list
-    constexpr int AHEAD = KL <= 2 ? 8 : (KL <= 4 ? 4 : 2);
-    for (int j0 = 1; j0 < nl; j0 += AHEAD) {
-        uint64_t b[AHEAD][KL];
-#pragma unroll
-        for (int u = 0; u < AHEAD; u++) wl_load_reversed<KL>(b[u], src + (size_t)(j0 + u < nl ? j0 + u : j0) * k, j0 + u < nl ? k : 0, lane);
-#pragma unroll
-        for (int u = 0; u < AHEAD; u++)
-            if (j0 + u < nl) wl_merge<KL>(a, b[u], lane);
-    }
-    if (!FINAL) {
-        uint64_t *o = out_keys + ((size_t)q * P2 + grp) * k;
-#pragma unroll
-        for (int e = 0; e < KL; e++) {
-            const int i = e * 64 + lane;
-            if (i < k) o[i] = a[e];
-        }
-    } else {
-        int cnt = 0;
-#pragma unroll
-        for (int e = 0; e < KL; e++) {
-            const int i = e * 64 + lane;
-            const bool have = i < k && a[e] != HVS_KEY_EMPTY;
-            cnt += __popcll(__ballot(have));
-            if (i < k) {
-                float d = __builtin_inff();
-                int64_t id = -1;
-                if (have) {
-                    d = hvs_unord((uint32_t)(a[e] >> 32));
-                    const uint32_t row = (uint32_t)a[e];
-                    id = ids ? ids[row] : (int64_t)row;
-                }
-                out_dist[(size_t)q * k + i] = d;
-                out_ids[(size_t)q * k + i] = id;
-            }
-        }
-        if (lane == 0) out_count[q] = cnt;
-    }
+    block_merge<KL>(a, in + ((size_t)q * P + first) * k, P - first < MERGE_BLOCK_FAN ? P - first : MERGE_BLOCK_FAN, k, handed, wave, lane);
+    if (wave > 0) return;
+    if (!FINAL) merged_to_keys<KL>(a, out_keys + ((size_t)q * P2 + grp) * k, k, lane);
+    else merged_to_results<KL>(a, k, ids, out_dist + (size_t)q * k, out_ids + (size_t)q * k, out_count + q, lane);
 }
 
 template <int KL>
 static int reduce_lists_kl(hvs_index *idx, uint64_t *bufA, uint64_t *bufB, int nq, int P, int k, float *d_dist,
                            int64_t *d_ids, int32_t *d_count, bool positions) {
     uint64_t *in = bufA, *out = bufB;
-    while (P > MERGE_FAN) {
-        const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
-        merge_lists_kernel<KL, false><<<dim3(P2, nq), 64, 0, idx->stream>>>(in, P, k, out, nullptr, nullptr, nullptr, nullptr);
+    while (P > MERGE_BLOCK_FAN) {
+        const int P2 = (P + MERGE_BLOCK_FAN - 1) / MERGE_BLOCK_FAN;
+        merge_lists_kernel<KL, false><<<dim3(P2, nq), 64 * MERGE_WAVES, 0, idx->stream>>>(in, P, k, out, nullptr, nullptr, nullptr, nullptr);
         HVS_HIP(hipGetLastError());
         uint64_t *t = in; in = out; out = t;
         P = P2;
     }
-    merge_lists_kernel<KL, true><<<dim3(1, nq), 64, 0, idx->stream>>>(in, P, k, nullptr, (positions || idx->emit_positions) ? nullptr : idx->ids, d_dist,
-                                                                      d_ids, d_count);
+    merge_lists_kernel<KL, true><<<dim3(1, nq), 64 * MERGE_WAVES, 0, idx->stream>>>(in, P, k, nullptr, (positions || idx->emit_positions) ? nullptr : idx->ids,
+                                                                                   d_dist, d_ids, d_count);
     HVS_HIP(hipGetLastError());
     return 0;
 }
@@ -784,15 +866,15 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         memset(&dummy, 0, sizeof(dummy));
         HVS_TRY(launch_scan<false>(idx->dtype, NQ, lpr, want_blocks, lds, idx->stream, dummy, &grid, true));
     }
-    const int P = grid * SCAN_WAVES;  // one list per wave
-    const int P2 = (P + MERGE_FAN - 1) / MERGE_FAN;
+    const int P = grid;  // one list per block
+    const int P2 = (P + MERGE_BLOCK_FAN - 1) / MERGE_BLOCK_FAN;
     void *bufA = nullptr, *bufB = nullptr;
     if (lists) {
         // per_pass only bounds how many of the kernel's NQ dot products a launch uses: the kernel and its LDS stay as sized
         auto need = [&](int pp) { return (((size_t)pp * P * k * 8 + 255) & ~(size_t)255) + (size_t)pp * P2 * k * 8; };
         while (per_pass > 1 && need(per_pass) > lists_bytes) per_pass--;
         HVS_REQUIRE(need(per_pass) <= lists_bytes,
-                    "hvs_search_noalloc: k = %d needs %zu bytes for the %d wave lists of one query and their first merge level, the "
+                    "hvs_search_noalloc: k = %d needs %zu bytes for the %d block lists of one query and their first merge level, the "
                     "scratch array leaves %zu",
                     k, need(1), P, lists_bytes);
         bufA = lists;
@@ -803,6 +885,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     }
 
     ScanParams p;
+    memset(&p, 0, sizeof(p));
     p.rows = idx->rows;
     p.inv_norm = idx->inv_norm;
     p.groups = idx->groups;

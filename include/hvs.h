@@ -251,13 +251,14 @@ int hvs_range_search_filtered(hvs_index *idx, const float *queries, int fold, co
  * hvs_search for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  No counterpart in the reference.  Same statement and the same answers as hvs_search with
  * on_device = 1 and HVS_ALGO_SCAN (the streaming scan; every pointer is memory of the index's GPU; returns after
- * the work has been submitted to the index's stream), but the prepared queries, the wave lists and the merge levels
+ * the work has been submitted to the index's stream), but the prepared queries, the block lists and the merge levels
  * live in one HVS_NOALLOC_SCRATCH_BYTES array inside the library's code object -- held by every GPU the library runs
  * on until the process ends -- and the call makes no hipMalloc / hipFree / allocating library call
  * (hvs_index_create looks the array's address up once per device).  Limits, refused with a message:
  * nq * fold * (4 * padded dim + 4) <= 1 MiB (170 embeddings of 1536 columns), and the lists of one query must fit
- * the rest: k * 8 bytes * 1.125 * (4 waves * resident blocks, at most 4096 lists) <= 7 MiB, i.e. k <= 199 on a
- * full grid, any k <= HVS_MAX_K on tables small enough for fewer blocks.  All calls on one GPU share that GPU's array:
+ * the rest: k * 8 bytes * (P + ceil(P / 32)) <= 7 MiB for the P lists of the scan's resident blocks and their first
+ * merge level, i.e. k <= 868 on a full grid of P = 1024, any k <= HVS_MAX_K where fewer blocks are resident (small
+ * tables; queries of several embeddings; k = 1024, whose lists leave room for three blocks per compute unit).  All calls on one GPU share that GPU's array:
  * calls that overlap on one GPU -- on different indexes or streams too -- race; serialise them.
  */
 #define HVS_NOALLOC_SCRATCH_BYTES (8u << 20)

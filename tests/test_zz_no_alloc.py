@@ -106,16 +106,16 @@ def test_limits_are_refused_with_a_message(hvs):
     idx = hvs.HvsIndex(d, "f32")
     idx.add(rng.standard_normal((n, d)).astype(np.float32))
     q = torch.from_numpy(rng.standard_normal((4, d)).astype(np.float32)).cuda()
-    k = 1024  # 4096 lists of 1024 keys do not fit 7 MiB
-    dist = torch.empty((4, k), dtype=torch.float32, device="cuda")
-    ids = torch.empty((4, k), dtype=torch.int64, device="cuda")
-    cnt = torch.empty((4,), dtype=torch.int32, device="cuda")
-    rc = lib.hvs_search_noalloc(idx._h, _ptr(q), 4, 1, k, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
+    k = 900  # one query: 1024 blocks are resident, and 1024 block lists of 900 keys do not fit 7 MiB
+    dist = torch.empty((1, k), dtype=torch.float32, device="cuda")
+    ids = torch.empty((1, k), dtype=torch.int64, device="cuda")
+    cnt = torch.empty((1,), dtype=torch.int32, device="cuda")
+    rc = lib.hvs_search_noalloc(idx._h, _ptr(q), 1, 1, k, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
     assert rc != 0 and b"scratch" in lib.hvs_last_error()
     # a small table runs fewer blocks, so the same k fits
     small = hvs.HvsIndex(d, "f32")
     small.add(rng.standard_normal((3000, d)).astype(np.float32))
-    ref, got = _both(hvs, small, q, 4, 1, k)
+    ref, got = _both(hvs, small, q, 4, 1, 1024)
     _same(ref, got, "k = 1024 on a small table")
     # too many query embeddings for the array's query region
     many = torch.zeros((8192, d), dtype=torch.float32, device="cuda")
@@ -132,7 +132,7 @@ def test_limits_are_refused_with_a_message(hvs):
 
 
 def test_limit_on_a_full_grid_is_the_documented_one(hvs):
-    """4096 wave lists (4 waves x 1024 resident blocks): k * 8 bytes * 1.125 per list must fit 7 MiB, i.e. k <= 199"""
+    """1024 block lists (the resident blocks) and the 32 lists of their first merge level: k * 8 bytes * 1056 must fit 7 MiB, i.e. k <= 868"""
     lib = hvs.load_library()
     rng = np.random.default_rng(6)
     n, d = 300_000, 64
@@ -141,13 +141,14 @@ def test_limit_on_a_full_grid_is_the_documented_one(hvs):
     idx.add(rows)
     q_host = rng.standard_normal((2, d)).astype(np.float32)
     q = torch.from_numpy(q_host).cuda()
-    ref, got = _both(hvs, idx, q, 2, 1, 199)
-    _same(ref, got, "k = 199")
-    parity.check_topk(got[0][1], got[1][1], got[2][1], parity.full_distances(rows, q_host[1], "f32"), 199, label="k = 199")
-    dist = torch.empty((2, 200), dtype=torch.float32, device="cuda")
-    ids = torch.empty((2, 200), dtype=torch.int64, device="cuda")
-    cnt = torch.empty((2,), dtype=torch.int32, device="cuda")
-    rc = lib.hvs_search_noalloc(idx._h, _ptr(q), 2, 1, 200, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
+    one = q[1:2].contiguous()  # one query per pass keeps four blocks per CU resident: the full grid
+    ref, got = _both(hvs, idx, one, 1, 1, 868)
+    _same(ref, got, "k = 868")
+    parity.check_topk(got[0][0], got[1][0], got[2][0], parity.full_distances(rows, q_host[1], "f32"), 868, label="k = 868")
+    dist = torch.empty((1, 869), dtype=torch.float32, device="cuda")
+    ids = torch.empty((1, 869), dtype=torch.int64, device="cuda")
+    cnt = torch.empty((1,), dtype=torch.int32, device="cuda")
+    rc = lib.hvs_search_noalloc(idx._h, _ptr(one), 1, 1, 869, -1, None, math.inf, 0, -1, _ptr(dist), _ptr(ids), _ptr(cnt))
     assert rc != 0 and b"scratch" in lib.hvs_last_error()
     idx.close()
 
