@@ -509,15 +509,15 @@ def child_leg(name, batch, timeout_s=600):
 def measured_traffic(rows_per_gpu, batch):
     """HBM-side bytes per launch of the search kernel from the committed counter passes (rocprofv3
     cannot be driven from inside this process); None when they were taken at another size."""
-    path = os.path.join(ROOT, "profiles", "r2_traffic.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh)["mfma_search_kernel"]
-    except (OSError, KeyError, ValueError):
-        return None, None
-    if t["rows_per_gpu"] != rows_per_gpu or t["batch"] != batch or t["dim"] != DIM:
-        return None, None
-    return t["bytes"], "profiles/r2_traffic.json: " + t["how"]
+    for name in ("r3_traffic.json", "r2_traffic.json"):  # the latest pass that covers this size
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                t = json.load(fh)["mfma_search_kernel"]
+        except (OSError, KeyError, ValueError):
+            continue
+        if t["rows_per_gpu"] == rows_per_gpu and t["batch"] == batch and t["dim"] == DIM:
+            return t["bytes"], f"profiles/{name}: " + t["how"]
+    return None, None
 
 
 def main():

@@ -17,7 +17,7 @@ probes)
   timeout -k 10 250 python3 tools/range_sweep.py > $OUT/range_sweep.txt 2>&1 || { tail -20 $OUT/range_sweep.txt; exit 1; }
   tail -14 $OUT/range_sweep.txt
   step "whole shard, batches"
-  timeout -k 10 250 python3 tools/whole_sweep.py > $OUT/whole_sweep.txt 2>&1 || { tail -20 $OUT/whole_sweep.txt; exit 1; }
+  timeout -k 10 250 python3 tools/whole_sweep.py 2000000 1536 f16 10 > $OUT/whole_sweep.txt 2>&1 || { tail -20 $OUT/whole_sweep.txt; exit 1; }
   tail -10 $OUT/whole_sweep.txt
   step "k beyond 256"
   timeout -k 10 200 python3 tools/large_k_probe.py > $OUT/large_k.txt 2>&1 || { tail -20 $OUT/large_k.txt; exit 1; }
