@@ -154,6 +154,7 @@ __global__ void fill_meta_kernel(int64_t *ids, int32_t *groups, int64_t n, int64
         int32_t g = 0;
         if (src_groups) g = src_groups[i];
         else if (n_groups > 0) g = (int32_t)(id % n_groups);
+        else if (n_groups < 0) g = (int32_t)((__int128)i * (-(int64_t)n_groups) / n);  // -n_groups equal runs, in order
         groups[first_pos + i] = g;
     }
 }

@@ -175,7 +175,10 @@ int hvs_index_export(hvs_index *idx, int64_t first, int64_t n, void *rows, int64
  * number first_global_row + r), column c is ((sum of the four 16-bit fields of
  * splitmix64((r*dim+c) ^ splitmix64(seed))) - 131070) * (1/37837), an
  * approximately N(0,1) value any host can regenerate bit for bit.  ids are the
- * global row numbers; group code = global row number mod n_groups.
+ * global row numbers; group code = global row number mod n_groups for
+ * n_groups > 0, 0 for n_groups = 0, and for n_groups < 0 the call's rows
+ * arrive in group order: -n_groups runs of equal length with codes 0, 1, ...
+ * (a bulk load ordered by workspace).
  * (Benchmark and parity-at-scale support; no reference counterpart.)
  */
 int hvs_index_fill_synthetic(hvs_index *idx, int64_t n, uint64_t seed, int64_t first_global_row,

@@ -198,3 +198,19 @@ def test_counting_sort_behind_the_kmeans_sums_takes_more_than_one_digit(hvs):
     np.add.at(exp_sums, assign[live], rows[live].astype(np.float64))
     assert np.abs(sums - exp_sums).max() <= 1e-4
     idx.close()
+
+
+def test_a_table_loaded_in_group_order_is_only_indexed(hvs):
+    """rows that arrive ordered by code (a bulk load by workspace): hvs_index_partition moves nothing and builds the ranges"""
+    n, d, runs = 10_007, 32, 7
+    idx = hvs.HvsIndex(d, "f16")
+    idx.fill_synthetic(n, seed=3, n_groups=-runs)
+    rows, ids, groups, deleted = idx.export()
+    assert np.array_equal(groups, (np.arange(n, dtype=np.int64) * runs // n).astype(np.int32))
+    old = idx.partition()
+    assert np.array_equal(old, np.arange(n)) and idx.partition_info() == (n, runs)
+    assert np.array_equal(idx.ids(), ids)
+    q = np.random.default_rng(2).standard_normal((5, d)).astype(np.float32)
+    for algo, nq in (("scan", 1), ("mfma", 5)):
+        _check(idx, rows, groups, np.zeros(n, bool), q[:nq], 10, 4, "f16", algo, ids, f"in-order {algo}")
+    idx.close()
