@@ -768,6 +768,14 @@ __global__ __launch_bounds__(64) void select_pooled_kernel(uint64_t *__restrict_
     if (lane == 0) out_count[q] = have;
 }
 
+// launch state of a search pass: 16-byte words [0, zero16) = 0, [zero16, all16) = all ones
+__global__ __launch_bounds__(256) void init_state_kernel(uint4 *__restrict__ p, size_t zero16, size_t all16) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < all16; i += (size_t)gridDim.x * 256) {
+        const uint32_t v = i < zero16 ? 0u : 0xFFFFFFFFu;
+        p[i] = make_uint4(v, v, v, v);
+    }
+}
+
 // LDS layout: [2 stages][tau][cnt][qinv][bound]
 template <class T> __device__ __forceinline__ BlockState block_state(char *smem, const SearchParams &p, int fold) {
     BlockState b;
@@ -1603,8 +1611,13 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         void *bufA = (char *)cand + ((cand_bytes + 255) & ~(size_t)255);
         int *overflow = (int *)((char *)bufB + keys_b);
         char *xc = (char *)overflow + up(64 + ls_bytes);
-        HVS_HIP(hipMemsetAsync(overflow, 0, up(64 + ls_bytes) + xc_bytes + pc_bytes, idx->stream));
-        if (xchg) HVS_HIP(hipMemsetAsync(xc + xc_bytes + pc_bytes, 0xFF, xv_bytes, idx->stream));
+        {
+            // flags and counters start at zero, the exchange tables behind them at all ones: one launch for both
+            const size_t zero16 = (up(64 + ls_bytes) + xc_bytes + pc_bytes) / 16, all16 = zero16 + xv_bytes / 16;
+            const int blocks = (int)((all16 + 255) / 256 < 512 ? (all16 + 255) / 256 : 512);
+            init_state_kernel<<<blocks, 256, 0, idx->stream>>>((uint4 *)overflow, zero16, all16);
+            HVS_HIP(hipGetLastError());
+        }
         pp.prof = (unsigned long long *)(overflow + 4);
         pp.lockstep = lockstep ? (unsigned int *)(overflow + 16) : nullptr;
         pp.pooled_count = pooled ? (unsigned int *)(xc + xc_bytes) : nullptr;
@@ -1616,7 +1629,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         pp.xchg_tau2 = (xchg && rounds > 1) ? (uint32_t *)(xc + xc_bytes + pc_bytes + x1_bytes + up((size_t)2 * 1024 * nq * 4)) : nullptr;
         pp.cand = (uint64_t *)cand;
         pp.partial = (uint64_t *)bufA;
-        pp.overflow = overflow;
+        idx->h_flag[0] = 0;  // (the stream is idle: every pass ends with a synchronisation)
+        pp.overflow = idx->h_flag;
         HVS_TRY(hvs_prof_begin(idx));
         if (stream) {
             if (kdt == HVS_F16) HVS_TRY(launch_stream_bm<HVS_F16>(bm, dual, pf, grid, idx->stream, pp));
@@ -1649,9 +1663,8 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         } else
             HVS_TRY(hvs_reduce_lists(idx, (uint64_t *)bufA, (uint64_t *)bufB, nq, S, k, o_dist, o_ids, o_count, hi_only));
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
-        int h_overflow = 0;
-        HVS_HIP(hipMemcpyAsync(&h_overflow, overflow, 4, hipMemcpyDeviceToHost, idx->stream));
         HVS_HIP(hipStreamSynchronize(idx->stream));
+        const int h_overflow = idx->h_flag[0];
         if (pp.dbg & 512) {
             unsigned long long h_prof[6] = {0, 0, 0, 0, 0, 0};
             HVS_HIP(hipMemcpy(h_prof, pp.prof, sizeof(h_prof), hipMemcpyDeviceToHost));

@@ -596,6 +596,12 @@ extern "C" int hvs_index_create(hvs_index **out, int device_id, int dim, int dty
     hipEventCreate(&idx->ev1);
     hipEventCreate(&idx->tm0);
     hipEventCreate(&idx->tm1);
+    if (hipHostMalloc((void **)&idx->h_flag, 64, hipHostMallocDefault) != hipSuccess) {
+        hvs_set_error("hvs_index_create: no pinned host memory for 64 bytes");
+        hvs_index_destroy(idx);
+        return 1;
+    }
+    idx->h_flag[0] = 0;
     *out = idx;
     return 0;
 }
@@ -615,6 +621,7 @@ extern "C" int hvs_index_destroy(hvs_index *idx) {
     hipFree(idx->split_rel);
     for (auto &w : idx->ws) hipFree(w.ptr);
     if (idx->h_pin) hipHostFree(idx->h_pin);
+    if (idx->h_flag) hipHostFree(idx->h_flag);
     hipEventDestroy(idx->ev0);
     hipEventDestroy(idx->ev1);
     hipEventDestroy(idx->tm0);

@@ -99,6 +99,8 @@ struct hvs_index {
                            // 10 the two lists of a (group range, tail) search
 
     void *h_pin = nullptr;  // pinned host buffer: the results of a search cross to the host in one copy
+    int *h_flag = nullptr;  // pinned host word the batched kernels raise when a candidate array overflows (never, by construction):
+                            // read after the stream has been synchronised, in place of a copy from the device per call
     size_t h_pin_bytes = 0;
 
     bool profiling = false;
