@@ -1839,8 +1839,11 @@ static int rescore_pass(hvs_index *idx, const float *d_q, const float *d_qinv, i
     HVS_HIP(hipGetLastError());
     HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     h_redo.assign(nq, 0);
-    HVS_HIP(hipMemcpyAsync(h_redo.data(), d_redo, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
+    void *pinned = nullptr;  // (a copy into pageable memory goes through the runtime's own staging and costs a second wait)
+    HVS_TRY(hvs_pinned_get(idx, (size_t)nq * 4, &pinned));
+    HVS_HIP(hipMemcpyAsync(pinned, d_redo, (size_t)nq * 4, hipMemcpyDeviceToHost, idx->stream));
     HVS_HIP(hipStreamSynchronize(idx->stream));
+    memcpy(h_redo.data(), pinned, (size_t)nq * 4);
     *n_redo = 0;
     for (int i = 0; i < nq; i++) *n_redo += h_redo[i] != 0;
     return 0;
