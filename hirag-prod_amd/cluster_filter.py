@@ -62,55 +62,51 @@ class ClusterFilter:
         self.distance_threshold = distance_threshold
         self.linkage_method = linkage_method
 
+    async def _stored_vectors(self, workspace_id: str, knowledge_base_id: str, chunk_ids: List[str]):
+        """(ids that have a stored vector, in the caller's order; their vectors as one matrix) -- the rows come from the GPU
+        table through ``query_by_keys`` / ``hvs_gather``"""
+        rows = await self.vdb.query_by_keys(key_value=chunk_ids, workspace_id=workspace_id, knowledge_base_id=knowledge_base_id,
+                                            table_name="Chunks", key_column="documentKey", columns_to_select=["documentKey", "vector"])
+        stored = {r["documentKey"]: r["vector"] for r in rows if r.get("documentKey") and r.get("vector") is not None}
+        ids = [cid for cid in chunk_ids if cid in stored]
+        if not ids:
+            return ids, None
+        return ids, np.array([stored[cid].to_list() if hasattr(stored[cid], "to_list") else list(stored[cid]) for cid in ids])
+
+    def _labels(self, features) -> np.ndarray:
+        if self.n_type == "fixed":
+            return ward_labels(features, n_clusters=self.n_clusters, linkage_method=self.linkage_method)
+        return ward_labels(features, n_clusters=None, distance_threshold=self.distance_threshold, linkage_method=self.linkage_method)
+
     async def apply_clustering(self, workspace_id: str, knowledge_base_id: str, chunk_ids: List[str]) -> Dict[str, Any]:
-        empty = {"clusters": {}, "chunk_ids": [], "cluster_info": {}}
+        """The payload of ``QueryService.apply_clustering`` (query_service.py:28-102): ``clusters`` maps ``cluster_<label>`` to
+        its chunk ids (labels in order of first appearance, ids in the caller's order); any failure gives the empty payload."""
+        nothing = {"clusters": {}, "chunk_ids": [], "cluster_info": {}}
         if not chunk_ids:
-            return empty
+            return nothing
         try:
-            rows = await self.vdb.query_by_keys(key_value=chunk_ids, workspace_id=workspace_id, knowledge_base_id=knowledge_base_id,
-                                                table_name="Chunks", key_column="documentKey",
-                                                columns_to_select=["documentKey", "vector"])
-            vectors = {}
-            for row in rows:
-                vec = row.get("vector")
-                if row.get("documentKey") and vec is not None:
-                    vectors[row["documentKey"]] = vec.to_list() if hasattr(vec, "to_list") else list(vec)
-            valid_ids = [cid for cid in chunk_ids if vectors.get(cid) is not None]
-            if not valid_ids:
+            ids, features = await self._stored_vectors(workspace_id, knowledge_base_id, chunk_ids)
+            if features is None:
                 logger.warning("No valid embeddings found in chunks")
-                return empty
-            features = np.array([vectors[cid] for cid in valid_ids])
-            if self.n_type == "fixed":
-                labels = ward_labels(features, n_clusters=self.n_clusters, linkage_method=self.linkage_method)
-            else:
-                labels = ward_labels(features, n_clusters=None, distance_threshold=self.distance_threshold,
-                                     linkage_method=self.linkage_method)
-            clusters: Dict[str, List[str]] = {}
-            for cid, label in zip(valid_ids, labels):
-                clusters.setdefault(f"cluster_{label}", []).append(cid)
-            return {"clusters": clusters, "chunk_ids": valid_ids,
-                    "cluster_info": {"n_clusters": len(np.unique(labels)), "total_chunks": len(valid_ids)}}
+                return nothing
+            labels = self._labels(features)
         except Exception as e:
             logger.error("Failed to apply clustering to chunks: %s", e)
-            return empty
+            return nothing
+        members = {f"cluster_{label}": [cid for cid, other in zip(ids, labels) if other == label] for label in dict.fromkeys(labels.tolist())}
+        return {"clusters": members, "chunk_ids": ids, "cluster_info": {"n_clusters": len(members), "total_chunks": len(ids)}}
 
     async def __call__(self, workspace_id: str, knowledge_base_id: str, chunks: List[Dict[str, Any]]) -> List[Dict[str, Any]]:
-        chunk_ids = [c.get("documentKey") for c in chunks if c.get("documentKey")]
-        clusters = (await self.apply_clustering(workspace_id, knowledge_base_id, chunk_ids)).get("clusters", {})
+        """``filter_chunks_by_cluster`` (query_service.py:104-153): of every cluster only the chunks carrying its newest
+        ``extractedTimestamp`` stay (all of them on a tie, a missing stamp counts as the oldest)."""
+        by_id = {c["documentKey"]: c for c in chunks if c.get("documentKey")}
+        keys_in_order = [c["documentKey"] for c in chunks if c.get("documentKey")]
+        clusters = (await self.apply_clustering(workspace_id, knowledge_base_id, keys_in_order)).get("clusters", {})
         if not clusters:
             return chunks
-        by_id = {c.get("documentKey"): c for c in chunks if c.get("documentKey")}
         kept: List[Dict[str, Any]] = []
         for keys in clusters.values():
-            latest: List[Dict[str, Any]] = []
-            latest_ts = datetime.min
-            for key in keys:
-                chunk = by_id.get(key)
-                if chunk:
-                    ts = chunk.get("extractedTimestamp", datetime.min) or datetime.min
-                    if not latest or ts > latest_ts:
-                        latest, latest_ts = [chunk], ts
-                    elif ts == latest_ts:
-                        latest.append(chunk)
-            kept.extend(latest)
+            group = [by_id[key] for key in keys if key in by_id]
+            stamps = [c.get("extractedTimestamp") or datetime.min for c in group]
+            kept.extend(c for c, stamp in zip(group, stamps) if stamp == max(stamps))
         return kept
