@@ -218,12 +218,11 @@ async def apply_reranking(query, results: List[dict], topk: int, topn: int, rera
     """src/hirag_prod/reranker/utils.py:6-26 with the reranker passed in (it is a remote service)."""
     if not results:
         return results
-    topn = min(topn, len(results))
-    topk = min(topk, len(results))
-    if topn > topk:
-        raise ValueError(f"topn ({topn}) must be <= topk ({topk})")
-    reranked = await reranker.rerank(query=query, items=results[:topk], key=key, rerank_with_time=rerank_with_time)
-    return reranked[:topn]
+    have = len(results)
+    head, keep = min(topk, have), min(topn, have)  # the reranker sees the first `head`, the caller gets `keep` of its answer
+    if keep > head:
+        raise ValueError(f"topn ({keep}) must be <= topk ({head})")
+    return (await reranker.rerank(query=query, items=results[:head], key=key, rerank_with_time=rerank_with_time))[:keep]
 
 
 def reset_weights(chunk_ids: Sequence[Optional[str]], triplets: Sequence[Dict[str, Any]], chunk_counts: Dict[str, int],
@@ -318,13 +317,11 @@ class FusionQueryService:
         # for objects shaped like the reference's.
         try:
             node = await self.gdb.query_node(ent, workspace_id, knowledge_base_id)
-            chunk_ids: List[str] = []
-            if hasattr(node, "metadata") and hasattr(node.metadata, "chunk_ids"):
-                chunk_ids = node.metadata.chunk_ids
-            return len(chunk_ids) if isinstance(chunk_ids, list) else 0
         except Exception as e:
             logger.error("Failed to fetch entity chunk count: %s", e)
             return 0
+        listed = getattr(getattr(node, "metadata", None), "chunk_ids", None)
+        return len(listed) if isinstance(listed, list) else 0
 
     async def pagerank_chunks(self, query: Union[str, List[str]], query_chunks: List[Dict[str, Any]], workspace_id: str,
                               knowledge_base_id: str, topk: Optional[int] = None, topn: Optional[int] = None,
