@@ -496,19 +496,47 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
 #pragma unroll
                 for (int q = 0; q < NQ; q++) part[r][q] = Chunk<DT>::zero();
 
-#pragma unroll 2
-            for (int c = l; c < p.chunks; c += LPR) {
+            // 16-bit rows, one embedding: the loads of the next chunk step go out before the products of this one are
+            // formed, so that a row pass keeps loads in flight throughout (a 300 MB range: 0.073 -> 0.067 ms).  The other
+            // kernels have no registers left for it under the four-waves-per-SIMD bound (fp32 rows with three embeddings
+            // lose 5 points of bandwidth to the spills) and fetch two chunk steps, then use them.
+            constexpr bool PIPELINED = DT != HVS_F32 && NQ == 1;
+            if constexpr (PIPELINED) {
+                auto fetch = [&](u32x4 (&v)[R], int c) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        v[r] = (u32x4){0u, 0u, 0u, 0u};
+                        if (live[r] && c < p.chunks) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                    }
+                };
                 u32x4 v[R];
+                fetch(v, l);
+#pragma unroll 2
+                for (int c = l; c < p.chunks; c += LPR) {
+                    u32x4 w[R];
+                    fetch(w, c + LPR);
+                    const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + (size_t)c * 16);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    v[r] = (u32x4){0u, 0u, 0u, 0u};
-                    if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                    for (int r = 0; r < R; r++) {
+                        part[r][0] = Chunk<DT>::dot(v[r], qv, part[r][0]);
+                        v[r] = w[r];
+                    }
                 }
+            } else {
+#pragma unroll 2
+                for (int c = l; c < p.chunks; c += LPR) {
+                    u32x4 v[R];
 #pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
+                    for (int r = 0; r < R; r++) {
+                        v[r] = (u32x4){0u, 0u, 0u, 0u};
+                        if (live[r]) v[r] = __builtin_nontemporal_load(rows16 + rowv[r] * p.chunks + c);
+                    }
 #pragma unroll
-                    for (int r = 0; r < R; r++) part[r][q] = Chunk<DT>::dot(v[r], qv, part[r][q]);
+                    for (int q = 0; q < NQ; q++) {
+                        const u32x4 qv = *reinterpret_cast<const u32x4 *>(q_lds + ((size_t)q * p.chunks + c) * 16);
+#pragma unroll
+                        for (int r = 0; r < R; r++) part[r][q] = Chunk<DT>::dot(v[r], qv, part[r][q]);
+                    }
                 }
             }
 #pragma unroll
