@@ -128,7 +128,8 @@ int hvs_index_compact(hvs_index *idx, int renumber_ids, int64_t *out_rows);
  * the row count before the call, or NULL) receives, for every new position, the position the row had.  renumber_ids:
  * ids become the new positions.  *out_rows (may be NULL) = the row count afterwards.  The rows move through new
  * arrays: the call needs as much free device memory as the table holds and fails, leaving the table as it was, when
- * that is not there.  Nearest thing in the reference: none (PostgreSQL would answer the same WHERE through a b-tree on
+ * that is not there.  A table without deleted rows whose codes already ascend (a bulk load ordered by workspace) is
+ * not moved: the call only builds its range table.  Nearest thing in the reference: none (PostgreSQL would answer the same WHERE through a b-tree on
  * the two columns, which the reference does not declare either); the step is CLUSTER for the HBM-resident table.
  */
 int hvs_index_partition(hvs_index *idx, int renumber_ids, int64_t *out_rows, int64_t *out_old_positions);
