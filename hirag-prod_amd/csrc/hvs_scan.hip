@@ -30,6 +30,8 @@ struct ScanParams {
     const float *queries;     // [nq_total, ld] fp32, pad columns zero
     const float *q_inv;       // [nq_total]
     int64_t row_begin, row_end;
+    int64_t row_begin2, row_end2;  // optional second range, scanned behind the first in the same launch with its own group test
+                                   // (group_filter2): a group's rows in the ordered part of a table, then the tail of rows added since
     int ld;       // row pitch in elements
     int chunks;   // 16-byte chunks per row
     int fold;     // embeddings folded by LEAST per output query
@@ -37,6 +39,7 @@ struct ScanParams {
     int k;
     uint32_t thr_ord;  // ordered-uint image of the strict distance bound
     int32_t group_filter;
+    int32_t group_filter2;
     uint64_t *partial;  // [nq_out, gridDim.x, k] keys (topk mode)
     float *dist_out;    // [row_end - row_begin] (distance mode)
 };
@@ -397,32 +400,45 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
     for (int q = 0; q < NQ; q++) { tau[q] = thr_key; cnt[q] = 0; }
 
     const u32x4 *rows16 = reinterpret_cast<const u32x4 *>(p.rows);
-    const int64_t n_groups = (p.row_end - p.row_begin + RG - 1) / RG;
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t nwaves = (int64_t)gridDim.x * SCAN_WAVES;
+    volatile uint32_t *rowq = row_queue + wave * (64 * RG);
 
-    // Without a filter this wave owns row groups gwave, gwave + nwaves, ... (RG rows each).  With a filter
+    // Up to two row ranges per launch, each walked in the way that suits it; the wave's lists carry over.
+    // Without a filter this wave owns row groups gwave, gwave + nwaves, ... (RG rows each) of a range.  With a filter
     // (group code, row mask, tombstones) it owns whole spans of 64 * RG consecutive rows instead: lane i
     // evaluates the filter of rows i, i + 64, ... of the span (consecutive lanes read consecutive filter
     // words: one cache line per load instruction, not one per lane), a wave prefix sum packs the surviving
-    // row numbers into a small LDS queue, and only those rows are streamed, RG at a time.
-    const bool filtered = !DISTONLY && (p.group_filter >= 0 || p.mask != nullptr || p.deleted != nullptr);
+    // row numbers into a small LDS queue, and only those rows are streamed, RG at a time.  (Spans suit filters that
+    // thin the rows out; a range whose rows all pass -- a group's range of a table in group order -- is better off
+    // without its test: a span of 64 * RG live rows is one wave's work.)
+#pragma unroll 1
+    for (int seg = 0; seg < 2; seg++) {
+    const int64_t seg_begin = seg ? p.row_begin2 : p.row_begin, seg_end = seg ? p.row_end2 : p.row_end;
+    if (seg_end <= seg_begin) continue;
+    const int32_t seg_group = seg ? p.group_filter2 : p.group_filter;
+    const int64_t n_groups = (seg_end - seg_begin + RG - 1) / RG;
+    const bool filtered = !DISTONLY && (seg_group >= 0 || p.mask != nullptr || p.deleted != nullptr);
     const int64_t my_groups = n_groups > gwave ? (n_groups - gwave + nwaves - 1) / nwaves : 0;
-    const int64_t n_spans = (p.row_end - p.row_begin + 64 * RG - 1) / (64 * RG);
+    // rows of a span per lane: RG on a range long enough to give every wave a span of 64 RG rows, fewer on a shorter one
+    // (down to spans of 64 rows), so that the waves share a short range instead of a few of them walking it alone
+    int per_lane = (int)((seg_end - seg_begin + 64 * nwaves - 1) / (64 * nwaves));
+    per_lane = per_lane < 1 ? 1 : (per_lane > RG ? RG : per_lane);
+    const int64_t span_rows = 64 * (int64_t)per_lane;
+    const int64_t n_spans = (seg_end - seg_begin + span_rows - 1) / span_rows;
     const int64_t n_outer = filtered ? (n_spans > gwave ? (n_spans - gwave + nwaves - 1) / nwaves : 0) : (my_groups + 63) / 64;
-    volatile uint32_t *rowq = row_queue + wave * (64 * RG);
     for (int64_t ob = 0; ob < n_outer; ob++) {
         const int64_t base = ob * 64;
         int n_items;
         int total = 0;
         if (filtered) {
             uint32_t mybits = 0;
-            const int64_t row0 = p.row_begin + (gwave + ob * nwaves) * (64 * RG) + lane;
+            const int64_t row0 = seg_begin + (gwave + ob * nwaves) * span_rows + lane;
 #pragma unroll
             for (int i = 0; i < RG; i++) {
                 const int64_t row = row0 + i * 64;
-                bool ok = row < p.row_end;
-                if (ok && p.group_filter >= 0) ok = p.groups[row] == p.group_filter;
+                bool ok = i < per_lane && row < seg_end;
+                if (ok && seg_group >= 0) ok = p.groups[row] == seg_group;
                 if (ok && p.mask) ok = (p.mask[row >> 5] >> (row & 31)) & 1u;
                 if (ok && p.deleted) ok = !((p.deleted[row >> 5] >> (row & 31)) & 1u);
                 mybits |= (ok ? 1u : 0u) << i;
@@ -457,8 +473,8 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
                 live[r] = qi < total;
                 rowv[r] = live[r] ? (int64_t)rowq[qi] : 0;
             } else {
-                rowv[r] = p.row_begin + (gwave + (base + it) * nwaves) * RG + r * SUB + sub;
-                live[r] = rowv[r] < p.row_end;
+                rowv[r] = seg_begin + (gwave + (base + it) * nwaves) * RG + r * SUB + sub;
+                live[r] = rowv[r] < seg_end;
             }
         }
         float acc[R][NQ];
@@ -636,6 +652,7 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
             }
         }
       }
+    }
     }
     if (DISTONLY) return;
 
@@ -865,9 +882,10 @@ static const size_t LDS_LIMIT = 160 * 1024;
 // lists / lists_bytes: where the wave lists and the merge levels go; nullptr = the index's growable workspaces 1 and 2.
 // With a caller's buffer nothing is allocated: the out-queries per pass shrink until the lists fit, and a search whose
 // lists do not fit even one query at a time is refused.
-int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
-                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
-                    int64_t *d_ids, int32_t *d_count, void *lists, size_t lists_bytes) {
+static int search_scan_ranges(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                              const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
+                              int64_t *d_ids, int32_t *d_count, void *lists, size_t lists_bytes, int64_t row_begin2, int64_t row_end2,
+                              int32_t group_filter2) {
     // out-queries per pass: as many as fit 8 dot products and the LDS budget -- or 4, for 16-bit rows with
     // two to four embeddings per query: those passes run the 4x4x4 MFMA mode, which stays bandwidth-bound
     const bool m4 = idx->dtype != HVS_F32 && fold <= 4 && nq * fold >= 2;
@@ -885,7 +903,9 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     const size_t lds = scan_lds_bytes(NQ, idx->ld, idx->elem_size, per_pass, k, rows_per_iter);
     HVS_REQUIRE(lds <= LDS_LIMIT, "hvs_search: dim %d with fold %d and k %d needs %zu bytes of LDS (limit %zu)", idx->dim, fold, k, lds, LDS_LIMIT);
 
-    const int64_t n_rows = row_end - row_begin;
+    // [row_begin2, row_end2): a second range for the same launch, under the group test group_filter2
+    const bool two_ranges = row_end2 > row_begin2;
+    const int64_t n_rows = (row_end - row_begin) + (two_ranges ? row_end2 - row_begin2 : 0);
     const int64_t row_groups = (n_rows + rows_per_iter - 1) / rows_per_iter;
     const int64_t want_blocks = (row_groups + SCAN_WAVES - 1) / SCAN_WAVES;
     int grid = 0;
@@ -921,6 +941,8 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     p.deleted = idx->n_deleted > 0 ? idx->deleted : nullptr;
     p.row_begin = row_begin;
     p.row_end = row_end;
+    p.row_begin2 = two_ranges ? row_begin2 : 0;
+    p.row_end2 = two_ranges ? row_end2 : 0;
     p.ld = idx->ld;
     p.chunks = chunks;
     p.fold = fold;
@@ -933,6 +955,7 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         p.thr_ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
     }
     p.group_filter = group_filter;
+    p.group_filter2 = group_filter2;
     p.partial = (uint64_t *)bufA;
     p.dist_out = nullptr;
 
@@ -952,6 +975,13 @@ int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
     }
     return 0;
+}
+
+int hvs_search_scan(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
+                    const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
+                    int64_t *d_ids, int32_t *d_count, void *lists, size_t lists_bytes) {
+    return search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, lists,
+                              lists_bytes, 0, 0, -1);
 }
 
 int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
@@ -1035,6 +1065,15 @@ static int search_range(hvs_index *idx, const float *d_q, const float *d_qinv, i
                                 nullptr, 0));
 
     return 0;
+}
+
+// Would search_range send this search to the scan?  (The cases in which a group filter is set: the filter route for
+// single queries on large fp32 tables takes no WHERE.)
+static bool filtered_search_takes_scan(hvs_index *idx, int nq, int fold, int k, int algo) {
+    if (algo == HVS_ALGO_SCAN) return true;
+    if (algo != HVS_ALGO_AUTO) return false;
+    const bool f32_pipe = idx->dtype == HVS_F32 && !(idx->split && idx->split_n == idx->n && !getenv("HVS_NO_SPLIT"));
+    return nq * fold < (f32_pipe ? 16 : 5) || !hvs_mfma_supported(idx, nq, fold, k);
 }
 
 // out = the k smallest of two ascending (distance, row position) lists per query, positions mapped to ids.  One block
@@ -1123,9 +1162,13 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
         const int64_t mb = row_begin > gb ? row_begin : gb, me = row_end < ge ? row_end : ge;
         const int64_t tb = row_begin > idx->part_n ? row_begin : idx->part_n, te = row_end;
         const bool have_main = mb < me, have_tail = tb < te;
-        if (have_main && have_tail) {
-            // both: each into lists of row positions, then one merge by (distance, position) -- the ordered part lies
-            // below the tail, so ties still go to the lower position
+        if (have_main && have_tail && filtered_search_takes_scan(idx, nq, fold, k, algo)) {
+            // both, on the scan: one launch walks the group's range (no code test) and then the tail (with it).  Keys order
+            // by row position, and the ordered part lies below the tail.
+            HVS_TRY(search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, d_dist, d_ids, d_count, nullptr, 0, tb, te, group_filter));
+        } else if (have_main && have_tail) {
+            // both, on the matrix pipe: each into lists of row positions, then one merge by (distance, position) -- the
+            // ordered part lies below the tail, so ties still go to the lower position
             auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
             const size_t o_i = up(dist_bytes), o_c = o_i + up(ids_bytes), one = o_c + up(cnt_bytes);
             void *pair = nullptr;
@@ -1223,20 +1266,25 @@ extern "C" int hvs_search_noalloc(hvs_index *idx, const float *queries, int nq, 
     float *d_q = (float *)scratch, *d_qinv = (float *)(scratch + inv_off);
     prep_queries_kernel<<<(nq_total + 3) / 4, 256, 0, idx->stream>>>(queries, d_q, d_qinv, nq_total, idx->dim, idx->ld, idx->dtype);
     HVS_HIP(hipGetLastError());
-    // a table in group order: the group's row range in place of the per-row test, when no rows have arrived since
-    // (a tail would need a second pass and a merge, whose lists this call has no room for)
-    int64_t gb = 0, ge = 0;
-    if (group_filter >= 0 && idx->part_n >= row_end && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, group_filter, &gb, &ge)) {
+    // a table in group order: the group's row range, and behind it in the same launch the tail of rows added since (those
+    // keep the per-row test); without a tail the test is dropped
+    int64_t gb = 0, ge = 0, tail_begin = 0, tail_end = 0;
+    int32_t tail_group = -1;
+    if (group_filter >= 0 && !getenv("HVS_NO_PARTITION") && hvs_part_range(idx, group_filter, &gb, &ge)) {
+        tail_begin = row_begin > idx->part_n ? row_begin : idx->part_n;
+        tail_end = row_end;
         row_begin = row_begin > gb ? row_begin : gb;
         row_end = row_end < ge ? row_end : ge;
         if (row_begin > row_end) row_begin = row_end;
+        if (tail_begin >= tail_end) tail_begin = tail_end = 0;
+        tail_group = group_filter;
         group_filter = -1;
     }
     // every wave of the scan writes all k keys of its list and every merge level writes all of its outputs, so nothing
     // in the array has to start at zero: what the previous call left is overwritten before it is read
-    return hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, row_mask, hvs_ceil_to_float(max_distance), row_begin, row_end,
-                           out_dist, out_ids, out_count, scratch + HVS_NOALLOC_QUERY_BYTES,
-                           HVS_NOALLOC_SCRATCH_BYTES - HVS_NOALLOC_QUERY_BYTES);
+    return search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, group_filter, row_mask, hvs_ceil_to_float(max_distance), row_begin, row_end,
+                              out_dist, out_ids, out_count, scratch + HVS_NOALLOC_QUERY_BYTES,
+                              HVS_NOALLOC_SCRATCH_BYTES - HVS_NOALLOC_QUERY_BYTES, tail_begin, tail_end, tail_group);
 }
 
 int hvs_distances_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int m, int64_t row_begin, int64_t row_end, float *d_out,

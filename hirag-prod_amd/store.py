@@ -279,14 +279,17 @@ class _SearchCoalescer:
     """
 
     MAX_BATCH = 1024  # requests per launch
+    INLINE_BELOW = 0.4e-3  # seconds: a table whose last launch was shorter than this is served on the loop's own thread
 
     def __init__(self, run_batch: Callable):
-        self._run_batch = run_batch  # (key, [q, ...]) -> [result, ...]; blocking, runs in a thread
+        self._run_batch = run_batch  # (key, [q, ...]) -> [result, ...]; blocking
         self._pending: Dict[tuple, list] = {}
         self._worker: Optional[asyncio.Task] = None
         self._loop = None
+        self._last_launch: Dict[Any, float] = {}  # table -> seconds its last launch took
         self.launches = 0
         self.requests = 0
+        self.inline_launches = 0
 
     async def submit(self, key: tuple, q: np.ndarray):
         loop = asyncio.get_running_loop()
@@ -315,8 +318,21 @@ class _SearchCoalescer:
             await asyncio.gather(*[self._serve(key, batch) for key, batch in round_])
 
     async def _serve(self, key: tuple, batch: list) -> None:
+        def timed(qs):
+            t0 = time.perf_counter()
+            out = self._run_batch(key, qs)
+            self._last_launch[key[0]] = time.perf_counter() - t0
+            return out
+
         try:
-            results = await asyncio.to_thread(self._run_batch, key, [q for q, _ in batch])
+            # A launch normally runs in a thread, so that the loop keeps taking requests (they form the next batch).  Handing
+            # a launch to a thread and hearing back costs about 0.2 ms, though: a search over a small table or a group's row
+            # range is shorter than that, and blocks the loop for less than the hand-over would take.
+            if self._last_launch.get(key[0], 1.0) < self.INLINE_BELOW:
+                results = timed([q for q, _ in batch])
+                self.inline_launches += 1
+            else:
+                results = await asyncio.to_thread(timed, [q for q, _ in batch])
             self.launches += 1
             self.requests += len(batch)
             for (_, fut), res in zip(batch, results):

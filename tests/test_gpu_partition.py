@@ -214,3 +214,40 @@ def test_a_table_loaded_in_group_order_is_only_indexed(hvs):
     for algo, nq in (("scan", 1), ("mfma", 5)):
         _check(idx, rows, groups, np.zeros(n, bool), q[:nq], 10, 4, "f16", algo, ids, f"in-order {algo}")
     idx.close()
+
+
+def test_range_and_tail_in_one_scan_launch_and_a_dense_filtered_range(hvs):
+    """a single query on a table with an ordered part and a tail is one scan launch (range without the code test, tail
+    with it); a filtered scan over a short range whose rows all pass shares the range among the waves"""
+    from hirag_prod_amd import _lib
+
+    rng = np.random.default_rng(31)
+    n, d, dtype = 60_000, 64, "f16"
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    groups = (np.arange(n) % 5).astype(np.int32)
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows[:45_000], group_codes=groups[:45_000])
+    idx.partition()
+    idx.add(rows[45_000:], ids=np.arange(45_000, n), group_codes=groups[45_000:])
+    dead = np.zeros(n, bool)
+    q = rng.standard_normal((6, d)).astype(np.float32)
+    for fold, nq in ((1, 1), (3, 1), (1, 4)):
+        idx.profile(True)
+        idx.profile_reset()
+        _check(idx, rows, groups, dead, q[: nq * fold], 10, 2, dtype, "auto", np.arange(n), f"one launch fold={fold}", fold=fold)
+        launches = idx.profile_get(_lib.HVS_PROF_SCAN)[1]
+        idx.profile(False)
+        assert launches == 1, f"range + tail took {launches} scan launches"
+    # tombstones in both parts: the range is walked in spans too
+    pos_of_id = {int(v): p for p, v in enumerate(idx.ids())}
+    gone = rng.choice(n, 900, replace=False)
+    dead[gone] = True
+    idx.set_deleted(np.asarray([pos_of_id[int(v)] for v in gone]))
+    for g in (2, 4):
+        _check(idx, rows, groups, dead, q[:3], 10, g, dtype, "scan", np.arange(n), f"tombstones g={g}")
+    _check(idx, rows, groups, dead, q[:3], 10, 3, dtype, "scan", np.arange(n), "tombstones fold", fold=3)
+    # no filter at all on a tombstoned table: every row of a short range is live but for a few
+    dist, ids, cnt = idx.search(q[:2], k=10, algo="scan")
+    for i in range(2):
+        parity.check_topk(dist[i], ids[i], cnt[i], parity.full_distances(rows, q[i], dtype), 10, keep=~dead, label=f"dense q={i}")
+    idx.close()

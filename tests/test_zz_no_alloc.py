@@ -170,13 +170,15 @@ def test_a_table_in_group_order_answers_from_the_row_range(hvs):
     for i in range(3):
         parity.check_topk(got[0][i], got[1][i], got[2][i], parity.full_distances(rows, q_host[i], "f16"), 20, keep=groups == 4,
                           label=f"group range q={i}")
-    # rows behind the ordered part: the call keeps the per-row test over the whole table (no room for a second list)
+    # rows behind the ordered part: one launch walks the group's range and then the tail, which keeps the per-row test
     extra = rng.standard_normal((500, d)).astype(np.float32)
-    idx.add(extra, ids=np.arange(n, n + 500), group_codes=np.full(500, 4, np.int32))
+    extra[17] = rows[np.flatnonzero(groups == 4)[0]]  # a tie between the ordered part and the tail
+    extra_groups = np.where(np.arange(500) % 3 == 0, 2, 4).astype(np.int32)
+    idx.add(extra, ids=np.arange(n, n + 500), group_codes=extra_groups)
     ref, got = _both(hvs, idx, q, 3, 1, 20, group=4)
     _same(ref, got, "group range + tail")
     all_rows = np.concatenate([rows, extra])
-    keep = np.concatenate([groups == 4, np.ones(500, bool)])
+    keep = np.concatenate([groups == 4, extra_groups == 4])
     for i in range(3):
         parity.check_topk(got[0][i], got[1][i], got[2][i], parity.full_distances(all_rows, q_host[i], "f16"), 20, keep=keep,
                           label=f"tail q={i}")
