@@ -69,6 +69,20 @@ def one_round(rng, label):
                 parity.check_topk(dist[i], ids[i], cnt[i], full, k, threshold=None if math.isinf(thr) else thr, keep=keep,
                                   label=f"{label} {dtype} {algo} dim={dim} n={n} first={first} ordered={ordered} nq={nq} fold={fold} k={k} gf={gf} thr={thr} q={i}")
                 checks += 1
+    # range search: every live row of the group below the bound, in ascending position
+    if n <= 150_000:
+        fold = int(rng.choice([1, 2]))
+        q = rng.standard_normal((fold, dim)).astype(np.float32)
+        gf = -1 if rng.random() < 0.5 else int(rng.integers(0, n_groups))
+        bound = float(rng.uniform(0.6, 1.0))
+        full = po.least_fold(parity.distance_matrix(rows, q, dtype))
+        keep = ~dead & ((groups == gf) if gf >= 0 else True)
+        rd, ri, total = idx.range_search(q, bound, group_filter=gf)
+        sure = {int(i) for i in np.flatnonzero(keep & (full < bound - 2e-6))}
+        maybe = {int(i) for i in np.flatnonzero(keep & (full < bound + 2e-6))}
+        got = set(ri.tolist())
+        assert sure <= got <= maybe and total == len(ri), f"{label} range search {dtype} dim={dim} n={n} gf={gf} bound={bound}: {len(got)} rows, {len(sure)}..{len(maybe)} expected"
+        checks += 1
     idx.close()
     return f"{dtype} dim={dim} n={n} groups={n_groups} ordered={ordered} tail={n - first} deleted={int(dead.sum())}: {checks} answers"
 
