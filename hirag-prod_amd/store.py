@@ -147,6 +147,10 @@ class _RowStore:
         for pos in range(len(alive)):
             yield _RowView(cols, names, pos) if alive[pos] else None
 
+    def live_positions(self) -> np.ndarray:
+        """Positions of the rows that are not deleted, ascending (int64) -- without building a view per row."""
+        return np.flatnonzero(np.frombuffer(bytes(self._alive), dtype=np.uint8)).astype(np.int64)
+
     def column(self, name):
         """The column's list, position-aligned (entries of deleted rows are None)."""
         return self._cols[name]
@@ -1010,7 +1014,7 @@ class HipVectorStore(BaseVDB):
     async def get_table(self, table_name: str) -> List[dict]:
         """Every live row with every column, vectors as lists (pgvector.py:685-702)."""
         table = self.get_model(table_name)
-        live = [pos for pos, row in enumerate(table.rows) if row is not None]
+        live = table.rows.live_positions().tolist()
         vecs = None
         if table.has_vector and table.index is not None and live:
             vecs = await asyncio.to_thread(table.index.gather, table.to_device(live))
@@ -1113,7 +1117,7 @@ class HipVectorStore(BaseVDB):
             for name in names:
                 table = self.get_model(name)
                 n = len(table.rows)
-                keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
+                keep = table.rows.live_positions()
                 if len(keep) != n:
                     if table.index is not None and (table.d2h is not None or table.part_rows):
                         await self._partition_table(table)
@@ -1160,7 +1164,7 @@ class HipVectorStore(BaseVDB):
         way stay valid unless deleted rows leave the host lists too, which renumbers them: only then does the epoch move."""
         index = table.index
         n = len(table.rows)
-        keep = np.asarray([pos for pos, row in enumerate(table.rows) if row is not None], dtype=np.int64)
+        keep = table.rows.live_positions()
         renumber = len(keep) != n
         if renumber:
             table.epoch += 1
