@@ -368,6 +368,7 @@ class HipVectorStore(BaseVDB):
         search_copy: bool = True,
         auto_partition: bool = True,
         partition_min_rows: int = 32768,
+        partition_tail_fraction: float = 0.25,
     ):
         """``search_copy``: a ``vector`` (fp32) table serves batched searches, single queries on large tables and
         k-means from a second, fp16-slab copy of its rows on the 16-bit matrix pipe -- several times faster, and as
@@ -377,8 +378,10 @@ class HipVectorStore(BaseVDB):
         ``auto_partition``: every ``query`` of the reference filters by (workspaceId, knowledgeBaseId)
         (``pgvector.py:577-580``); a table kept in the order of that pair answers the filter with a row range
         (``partition``).  With this set, a table is put in that order when the rows added since the last time are at
-        least ``partition_min_rows`` and at least as many as the ordered rows (so the copying stays proportional to the
-        table's growth); ``prepare`` does it whatever the size.
+        least ``partition_min_rows`` and at least ``partition_tail_fraction`` of the ordered rows: the copying stays
+        proportional to the table's growth (a quarter: every row moves about five times while a table grows, 27 ms per
+        move for 12.5M x 768 bf16 rows), and a filtered search never walks a tail longer than that fraction of the
+        table with the per-row test.  ``prepare`` orders a table whatever the size.
 
         ``vector_type`` None: the environment decides, as it does for the reference's column type
         (``USE_HALF_VEC``, true unless set otherwise -> ``halfvec``; ``schema/vector_config.py:8-11``).
@@ -410,6 +413,7 @@ class HipVectorStore(BaseVDB):
         self._copy_logged: Dict[str, int] = {}
         self.auto_partition = bool(auto_partition)
         self.partition_min_rows = int(partition_min_rows)
+        self.partition_tail_fraction = float(partition_tail_fraction)
 
     # the reference's factory convention: PGVector.create(embedding_func, vector_type) (pgvector.py:70-77)
     @classmethod
@@ -605,7 +609,7 @@ class HipVectorStore(BaseVDB):
                     table.pk_map[pk] = first + j
                     table.note_insert(first + j, stored)
                 tail = len(table.rows) - table.part_rows
-                if (self.auto_partition and len(self._group_codes) > 1 and tail >= max(self.partition_min_rows, table.part_rows)
+                if (self.auto_partition and len(self._group_codes) > 1 and tail >= max(self.partition_min_rows, int(table.part_rows * self.partition_tail_fraction))
                         and len(table.rows) >= 2 * table.part_failed_n and hasattr(index, "partition")):
                     try:
                         await self._partition_table(table)

@@ -542,8 +542,9 @@ async def scenario_partition(store, load_store, storage, directory):
     with_tail = await probe(store)
     for j, (ws, kb) in enumerate(spaces):
         oracle_check(with_tail[j], ws, kb, [f"text {ws} {kb} 12", f"text {ws} {kb} 40"], 12, 1.6, known, dead)
-    # the store's own rule: once the rows added since are as many as the ordered ones (and past the minimum) it orders the table
-    store.auto_partition, store.partition_min_rows = True, 30
+    # the store's own rule: once the rows added since are past the minimum and a set fraction of the ordered ones (here: as
+    # many) it orders the table
+    store.auto_partition, store.partition_min_rows, store.partition_tail_fraction = True, 30, 1.0
     await store.upsert_texts(texts[200:240], props[200:240], "Chunks")
     known = 240
     assert len(chunks.rows) - chunks.part_rows == 80  # 80 behind 107 ordered rows: not yet
