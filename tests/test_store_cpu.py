@@ -151,3 +151,37 @@ def test_env_names_of_the_reference_set_type_and_dimension(monkeypatch):
     s3 = st.HipVectorStore.create(store_cases.make_embedding_func(), index_factory=factory)
     with pytest.raises(ValueError, match="expected 5 dimensions"):
         store_cases.run(s3.upsert_texts(["a text"], [{"documentKey": "k", "workspaceId": "w", "knowledgeBaseId": "b"}], "Chunks"))
+
+
+def test_the_store_reorders_a_table_once_its_tail_is_a_quarter_of_the_ordered_rows():
+    """auto_partition: rows added since the last reordering >= partition_min_rows and >= partition_tail_fraction (0.25)
+    of the ordered rows"""
+    import hirag_prod_amd.store as st
+
+    s = st.HipVectorStore.create(store_cases.make_embedding_func(), vector_type="halfvec", partition_min_rows=20,
+                                 index_factory=lambda dim, dtype, device: OracleIndex(dim, dtype, device))
+    assert s.partition_tail_fraction == 0.25
+
+    async def go():
+        await s._init_vdb(embedding_dimension=store_cases.DIM)
+        chunks = s.tables["Chunks"]
+
+        async def add(first, n):
+            props = [store_cases.chunk_props(i, ws=f"ws{i % 3}") for i in range(first, first + n)]
+            await s.upsert_texts([p["text"] for p in props], props, "Chunks")
+
+        await add(0, 10)  # one workspace would need no order; three do, but 10 rows are below the minimum
+        assert chunks.part_rows == 0
+        await add(10, 90)
+        assert chunks.part_rows == 100  # 100 rows behind none
+        await add(100, 20)
+        assert chunks.part_rows == 100  # 20 < 25 = a quarter of 100
+        await add(120, 5)
+        assert chunks.part_rows == 125  # 25 behind 100
+        await add(125, 25)
+        assert chunks.part_rows == 125  # 25 < 31
+        res = await s.query("text ws1 kb1 130", "ws1", "kb1", "Chunks", topk=1, topn=1)
+        assert res[0]["chunkIdx"] == 130  # a row of the tail
+
+    store_cases.run(go())
+    s.close()
