@@ -281,6 +281,22 @@ def leg_cfg5(hvs, _lib, torch, dev, n=12_500_000, first_global_row=25_000_000, w
             "kernel_GBps_of_live_bytes": live * d * 2 / (kern["median_ms"] * 1e-3) / 1e9,
             "kernel_TFLOPs": 2.0 * nq * live * d / (kern["median_ms"] * 1e-3) / 1e12,
         }
+    if not arrives_in_order and "rows_in_order" in out.get("group_order", {}):
+        # rows that arrive after the table was put in order form a tail behind it (the store reorders once the tail is a
+        # quarter of the table): 5 % more rows, then the filtered calls again -- one scan launch over range + tail for the
+        # single query, range and tail separately plus a merge for the batch
+        extra = n // 20
+        idx.fill_synthetic(extra, seed=SEED_CORPUS, first_global_row=first_global_row + n, n_groups=64)
+        tail = {"rows_behind_the_ordered_part": extra}
+        for label, nq, algo, which in (("single_query_workspace_filter", 1, "scan", _lib.HVS_PROF_SCAN),
+                                       ("batch_256_workspace_filter", 256, "mfma", _lib.HVS_PROF_MFMA_SEARCH)):
+            qq = q[:nq].contiguous()
+
+            def g():
+                idx.search(qq, k=k, algo=algo, group_filter=3)
+
+            tail[label] = {"call": stats_ms(timed_calls(torch, g, 20)), "kernel": stats_ms(kernel_ms(idx, which, g, torch, 20, per_call=True))}
+        out["with_a_tail_of_5_percent"] = tail
     idx.close()
     return out
 

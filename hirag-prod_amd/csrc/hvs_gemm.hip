@@ -1533,6 +1533,31 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (const char *e = getenv("HVS_F32_TILE")) big = kdt == HVS_F32 ? atoi(e) == 256 && nA > Tile128::BM : big;  // 128 / 256 forces the shape for fp32 rows
     bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
     if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
+    // A range so short that the blocks of the tile at hand could not pool their first tiles (fewer than 2 k published
+    // values per query) takes a smaller tile that can: without a common bound every score of such a launch is a survivor
+    // (the dense copy of 9 800 live rows of a tail, 256 queries, k = 100: 0.39 ms on 32 blocks of the 256 x 256 tile).
+    if (!stream && kdt != HVS_F32 && !getenv("HVS_TILE") && !getenv("HVS_NO_XCHG")) {
+        const int64_t rows = row_end - row_begin;
+        auto splits_with = [&](int bm_, int bn_, int slots_) {
+            const int qt = (nA + bm_ - 1) / bm_;
+            const int64_t T_ = (rows + bn_ - 1) / bn_;
+            int64_t S_ = ((slots_ + qt - 1) / qt + 7) / 8 * 8;
+            if (S_ > T_) S_ = T_;
+            if (S_ >= 8) S_ = S_ / 8 * 8;
+            return S_ < 1 ? (int64_t)1 : S_;
+        };
+        auto is_short = [&](int bm_, int slots_) { return (int64_t)k * 8192 > rows / ((slots_ + (nA + bm_ - 1) / bm_ - 1) / ((nA + bm_ - 1) / bm_)); };
+        auto can_pool = [&](int bm_, int bn_, int slots_, int wn_) {
+            const int64_t S_ = splits_with(bm_, bn_, slots_);
+            return (int64_t)((nA + bm_ - 1) / bm_) * S_ <= slots_ && S_ <= 1024 && S_ * wn_ >= 2 * k && (S_ * wn_ <= 1024 || S_ >= 2 * k);
+        };
+        if (big && is_short(Tile256::BM, 256) && !can_pool(Tile256::BM, Tile256::BN, 256, Tile256::WN)) {
+            if (can_pool(Tile128::BM, Tile128::BN, 512, Tile128::WN)) big = false;
+            else if (can_pool(Tile64::BM, Tile64::BN, 1024, Tile64::WN)) big = false, small = true;
+        } else if (!big && !small && is_short(Tile128::BM, 512) && !can_pool(Tile128::BM, Tile128::BN, 512, Tile128::WN) &&
+                   can_pool(Tile64::BM, Tile64::BN, 1024, Tile64::WN))
+            small = true;
+    }
     const int bm = stream ? (nA <= 32 ? 32 : (nA <= 64 ? 64 : 128)) : (big ? Tile256::BM : (small ? Tile64::BM : Tile128::BM));
     const int bn = stream ? 256 : (big ? Tile256::BN : (small ? Tile64::BN : Tile128::BN));
     // ring kernel on the split copy: up to 64 rows both query slabs ride in a stage -- (A hi, A lo | X hi) steps, then
@@ -1608,7 +1633,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         const size_t x1_bytes = up((size_t)nq * xm * 4) + up((size_t)nq * 4);
         const size_t x2_bytes = rounds > 1 ? up((size_t)2 * 1024 * nq * 4) + up((size_t)2 * nq * 4) : 0;
         const size_t xv_bytes = xchg ? x1_bytes + x2_bytes : 0;
-        const bool pooled = xchg || k > MFMA_MAX_K;  // one list per query that every block appends to, ranked by select_pooled_kernel
+        // one list per query that every block appends to, ranked by select_pooled_kernel: where the blocks pool their bounds,
+        // where k is beyond the sorted lists, and wherever a block's stream is so short that most of what it scores survives --
+        // sorting a full candidate array per query and block then costs more than the contraction (a dense copy of 9 800 rows,
+        // 256 queries, k = 100: 39 blocks of one tile each spent 0.43 ms on it)
+        const bool pooled = xchg || k > MFMA_MAX_K || tiles_per_block <= 8;
         const size_t pc_bytes = pooled ? up((size_t)nq * 4) : 0;  // its counters, zeroed with the overflow flag
         const size_t keys_b = up((size_t)nq * P2 * k * 8);
         HVS_TRY(hvs_ws_get(idx, 1, cand_bytes + part_bytes + 512, &cand));
