@@ -344,7 +344,9 @@ __global__ __launch_bounds__(LIVE_THREADS) void live_rows_kernel(hvs_live_params
 }
 
 // Exclusive scan of n block counts by one block; offsets[n] = total.
-__global__ __launch_bounds__(1024) void live_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, int n) {
+// host_total: a pinned host word that receives the total as well (read after the stream's next synchronisation).
+__global__ __launch_bounds__(1024) void live_scan_kernel(const uint32_t *__restrict__ counts, uint32_t *__restrict__ offsets, int n,
+                                                         uint32_t *__restrict__ host_total) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024;
@@ -364,7 +366,10 @@ __global__ __launch_bounds__(1024) void live_scan_kernel(const uint32_t *__restr
         offsets[i] = run;
         run += counts[i];
     }
-    if (t == 1023) offsets[n] = part[1023];
+    if (t == 1023) {
+        offsets[n] = part[1023];
+        *host_total = part[1023];
+    }
 }
 
 // dst row i = src row positions[i] (16-byte chunks, one wave per row), with its inverse norm.
@@ -393,10 +398,11 @@ int hvs_live_count(hvs_index *idx, const hvs_live_params &lp, uint32_t *n_live) 
     HVS_TRY(hvs_ws_get(idx, 5, o_off + (size_t)(nb + 1) * 4, &cw));
     uint32_t *counts = (uint32_t *)cw, *offsets = (uint32_t *)((char *)cw + o_off);
     live_rows_kernel<false><<<nb, LIVE_THREADS, 0, idx->stream>>>(lp, counts, nullptr, nullptr);
-    live_scan_kernel<<<1, 1024, 0, idx->stream>>>(counts, offsets, nb);
+    volatile uint32_t *host_total = reinterpret_cast<volatile uint32_t *>(idx->h_flag) + 8;  // second half of the pinned line
+    live_scan_kernel<<<1, 1024, 0, idx->stream>>>(counts, offsets, nb, const_cast<uint32_t *>(host_total));
     HVS_HIP(hipGetLastError());
-    HVS_HIP(hipMemcpyAsync(n_live, offsets + nb, 4, hipMemcpyDeviceToHost, idx->stream));
     HVS_HIP(hipStreamSynchronize(idx->stream));
+    *n_live = *host_total;
     return 0;
 }
 
