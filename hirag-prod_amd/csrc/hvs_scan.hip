@@ -130,54 +130,111 @@ template <int DT> __device__ __forceinline__ f32x4v mfma4(const u32x4 &q, const 
     }
 }
 
-// ---- wave-private sorted list in LDS ------------------------------------------------------------
+// ---- wave-private list in LDS ------------------------------------------------------------
 __device__ __forceinline__ void wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-// Insert a wave-uniform key into the ascending list L[0..cnt) of capacity k.  All 64 lanes call it.
-__device__ __forceinline__ void wave_insert(volatile uint64_t *L, int &cnt, int k, uint64_t key, int lane) {
-    int pos = 0;
-    for (int base = 0; base < cnt; base += 64) {
-        const int i = base + lane;
-        const bool lt = (i < cnt) && (L[i] < key);
-        pos += __popcll(__ballot(lt));
+// A wave's list holds up to k keys in no particular order (keys are distinct: the low word is the row).  While it has room,
+// the keys below the bound are appended where they arrive, one LDS write for all the lanes' keys.  Once it is full, tau is its
+// largest key: a key below tau takes that key's slot and the largest is found again -- each lane the largest of its slots,
+// then six DPP steps over the lanes for the distance word and six for the row word.  The lists are put in order once, when the
+// wave has seen all its rows (wave_sort).  (A list kept in order costs several dependent LDS round trips per key, and until a
+// list is full every key below the bound is one: the first k rows of every wave, and on a short range, where a wave sees
+// fewer than k rows, all of them -- a 300 MB range of 768-column bf16 rows, k = 100: 48 rows per wave.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_umax_step(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);  // no source: the lane's own
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+    v = dpp_umax_step<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_umax_step<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_umax_step<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_umax_step<0x118, 0xF>(v);  // row_shr:8: lane 15 of every row of 16 lanes has the row's
+    v = dpp_umax_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_umax_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// The largest key of the full list L[0..k), after the slot that holds `out` (a key of the list, or HVS_KEY_EMPTY for none)
+// has taken `in`.
+__device__ __forceinline__ uint64_t wave_swap_largest(volatile uint64_t *L, int k, uint64_t out, uint64_t in, int lane) {
+    wave_fence();  // earlier writes to the list are in it
+    uint64_t m = 0;
+    for (int i = lane; i < k; i += 64) {
+        uint64_t v = L[i];
+        if (v == out) {
+            v = in;
+            L[i] = in;
+        }
+        m = v > m ? v : m;
     }
-    if (pos >= k) return;
-    const int newcnt = cnt < k ? cnt + 1 : k;
-    for (int base = ((newcnt - 1) >> 6) << 6; base >= ((pos >> 6) << 6); base -= 64) {
-        const int i = base + lane;
-        uint64_t v = 0;
-        bool w = false;
-        if (i > pos && i < newcnt) { v = L[i - 1]; w = true; }
-        else if (i == pos) { v = key; w = true; }
-        wave_fence();
-        if (w) L[i] = v;
-        wave_fence();
-    }
-    cnt = newcnt;
+    const uint32_t hi = wave_umax((uint32_t)(m >> 32));
+    const uint32_t lo = wave_umax((uint32_t)(m >> 32) == hi ? (uint32_t)m : 0u);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-// Offer one candidate key per lane (HVS_KEY_EMPTY = none) to the list; tau = current admission bound.
+// Offer one candidate key per lane (HVS_KEY_EMPTY = none) to the list; tau = current admission bound (the caller's bound
+// until the list is full).
 __device__ __forceinline__ void wave_offer(volatile uint64_t *L, int &cnt, int k, uint64_t &tau, uint64_t thr_key,
                                            uint64_t key, int lane) {
     uint64_t pending = __ballot(key < tau);
+    if (!pending) return;
+    if (cnt < k) {
+        const int room = k - cnt, n = __popcll(pending);
+        const int at = __popcll(pending & ((1ull << lane) - 1ull));
+        if (key < tau && at < room) L[cnt + at] = key;
+        if (n < room) {
+            cnt += n;
+            return;
+        }
+        cnt = k;
+        tau = wave_swap_largest(L, k, HVS_KEY_EMPTY, HVS_KEY_EMPTY, lane);
+        for (int i = 0; i < room; i++) pending &= pending - 1;  // those went in
+        pending &= __ballot(key < tau);
+    }
     while (pending) {
         const int src = __ffsll((unsigned long long)pending) - 1;
         pending &= pending - 1;
         const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)key, src);
         const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(key >> 32), src);
         const uint64_t c = ((uint64_t)hi << 32) | lo;
-        if (c < tau) {
-            wave_insert(L, cnt, k, c, lane);
-            if (cnt == k) {
-                wave_fence();
-                tau = L[k - 1];
-            }
-        }
+        if (c < tau) tau = wave_swap_largest(L, k, tau, c, lane);
     }
     (void)thr_key;
+}
+
+// Put the cnt <= 64 KL keys of a list in ascending order, in place: a key's place is the number of keys below it, counted
+// against every key of the list (one LDS broadcast read each).
+template <int KL> __device__ __forceinline__ void wave_sort_r(volatile uint64_t *L, int cnt, int lane) {
+    wave_fence();
+    const uint64_t *Lc = const_cast<const uint64_t *>(L);
+    uint64_t mine[KL];
+    int rank[KL];
+#pragma unroll
+    for (int e = 0; e < KL; e++) {
+        mine[e] = e * 64 + lane < cnt ? Lc[e * 64 + lane] : HVS_KEY_EMPTY;
+        rank[e] = 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < cnt; j++) {
+        const uint64_t o = Lc[j];
+#pragma unroll
+        for (int e = 0; e < KL; e++) rank[e] += o < mine[e] ? 1 : 0;
+    }
+    wave_fence();  // every lane has read what it needs
+#pragma unroll
+    for (int e = 0; e < KL; e++)
+        if (e * 64 + lane < cnt) L[rank[e]] = mine[e];
+    wave_fence();
+}
+__device__ __forceinline__ void wave_sort(volatile uint64_t *L, int cnt, int lane) {
+    if (cnt <= 1) return;
+    if (cnt <= 64) wave_sort_r<1>(L, cnt, lane);
+    else if (cnt <= 128) wave_sort_r<2>(L, cnt, lane);
+    else if (cnt <= 256) wave_sort_r<4>(L, cnt, lane);
+    else if (cnt <= 512) wave_sort_r<8>(L, cnt, lane);
+    else wave_sort_r<16>(L, cnt, lane);
 }
 
 // ---- dot-product reduction across the lanes of a row group ----------------------------------------
@@ -659,6 +716,9 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
     // publish: one ascending list of k keys per block and query (padded); the merge kernels do the rest.  The block's
     // four wave lists are merged where they lie, in LDS: a key's place in the union is its index in its own list plus
     // the number of keys before it in each of the others (keys carry the row number, so no two are equal).
+#pragma unroll
+    for (int qo = 0; qo < NQ; qo++)
+        if (qo < p.nq_out) wave_sort(myL + (size_t)qo * p.k, cnt[qo], lane);
     int *counts = reinterpret_cast<int *>(row_queue + wave * (64 * RG));  // the wave's own queue is free now
     if (lane < NQ) {
         int c = 0;
