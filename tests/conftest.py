@@ -37,3 +37,15 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _finalizers_between_tests(request):
+    """Objects caught in reference cycles (the traceback of an expected error keeps its frame's locals, an index among
+    them) are finalized here, between tests and with the GPU idle, not wherever the cyclic collector happens to run
+    inside a later test."""
+    yield
+    if "gpu" in request.keywords:
+        import gc
+
+        gc.collect()
