@@ -1328,6 +1328,21 @@ static int launch_search(int pf, int grid, hipStream_t st, const SearchParams &p
     return 0;
 }
 
+// Corpus splits of a two-stage launch over `tiles` corpus tiles with qt query tiles: fill every block slot of the chip
+// (2 per CU for the small tiles, 1 for the large), keep the count a multiple of 8 (XCD affinity) and every split non-empty.
+static int two_stage_splits(int qt, int64_t tiles, int slots) {
+    int S = (slots + qt - 1) / qt;
+    S = (S + 7) / 8 * 8;
+    if ((int64_t)S > tiles) S = (int)tiles;
+    if (S >= 8) S = S / 8 * 8;
+    return S < 1 ? 1 : S;
+}
+// Can the blocks of such a launch pool their first tiles (exchange_bound)?  Every block resident at once, at most 1024 and
+// at least 2 k published values per query (wn per block, or one per block where S * wn would pass 1024).
+static bool two_stage_can_pool(int qt, int S, int slots, int wn, int k) {
+    return (int64_t)qt * S <= slots && S <= 1024 && S * wn >= 2 * k && (S * wn <= 1024 || S >= 2 * k);
+}
+
 // LEAST over m <= 128 prepared embeddings of the distance to every row of [row_begin, row_end), in one pass over the
 // rows on the matrix pipe.  *used = false when this route does not apply (fp32 rows whose split copy is neither
 // current nor worth building); the caller then streams the rows once per 8 embeddings.
@@ -1538,18 +1553,10 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // (the dense copy of 9 800 live rows of a tail, 256 queries, k = 100: 0.39 ms on 32 blocks of the 256 x 256 tile).
     if (!stream && kdt != HVS_F32 && !getenv("HVS_TILE") && !getenv("HVS_NO_XCHG")) {
         const int64_t rows = row_end - row_begin;
-        auto splits_with = [&](int bm_, int bn_, int slots_) {
-            const int qt = (nA + bm_ - 1) / bm_;
-            const int64_t T_ = (rows + bn_ - 1) / bn_;
-            int64_t S_ = ((slots_ + qt - 1) / qt + 7) / 8 * 8;
-            if (S_ > T_) S_ = T_;
-            if (S_ >= 8) S_ = S_ / 8 * 8;
-            return S_ < 1 ? (int64_t)1 : S_;
-        };
         auto is_short = [&](int bm_, int slots_) { return (int64_t)k * 8192 > rows / ((slots_ + (nA + bm_ - 1) / bm_ - 1) / ((nA + bm_ - 1) / bm_)); };
         auto can_pool = [&](int bm_, int bn_, int slots_, int wn_) {
-            const int64_t S_ = splits_with(bm_, bn_, slots_);
-            return (int64_t)((nA + bm_ - 1) / bm_) * S_ <= slots_ && S_ <= 1024 && S_ * wn_ >= 2 * k && (S_ * wn_ <= 1024 || S_ >= 2 * k);
+            const int qt = (nA + bm_ - 1) / bm_;
+            return two_stage_can_pool(qt, two_stage_splits(qt, (rows + bn_ - 1) / bn_, slots_), slots_, wn_, k);
         };
         if (big && is_short(Tile256::BM, 256) && !can_pool(Tile256::BM, Tile256::BN, 256, Tile256::WN)) {
             if (can_pool(Tile128::BM, Tile128::BN, 512, Tile128::WN)) big = false;
@@ -1579,20 +1586,11 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     // corpus splits for a range of T tiles
     auto splits_of = [&](int64_t T) -> int {
         if (stream) return (int)(T < 256 ? T : 256);
-        // fill every block slot of the chip (2 per CU for the small tile, 1 for the large), keep S a multiple of 8 (XCD
-        // affinity) and every split non-empty
-        int S = (slots_of_tile + p.QT - 1) / p.QT;
-        S = (S + 7) / 8 * 8;
-        if ((int64_t)S > T) S = (int)T;
-        if (S >= 8) S = S / 8 * 8;
-        return S < 1 ? 1 : S;
+        return two_stage_splits(p.QT, T, slots_of_tile);
     };
     // can the blocks of such a launch pool their first tiles (exchange_bound)?  16-bit operands on the two-stage kernel,
     // every block resident at once, at most 1024 and at least 2 k published values per query
-    auto xchg_fits = [&](int S) -> bool {
-        return !stream && kdt != HVS_F32 && p.QT * S <= slots_of_tile && S <= 1024 && S * wn_of_tile >= 2 * k &&
-               (S * wn_of_tile <= 1024 || S >= 2 * k);
-    };
+    auto xchg_fits = [&](int S) -> bool { return !stream && kdt != HVS_F32 && two_stage_can_pool(p.QT, S, slots_of_tile, wn_of_tile, k); };
     // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
     auto run_pass = [&](SearchParams pp, int64_t rb, int64_t re, const float *tau0, float *o_dist, int64_t *o_ids, int32_t *o_count) -> int {
         pp.row_begin = rb;
