@@ -29,6 +29,9 @@ struct ScanParams {
     const uint32_t *deleted;  // optional: bit set = row deleted
     const float *queries;     // [nq_total, ld] fp32, pad columns zero
     const float *q_inv;       // [nq_total]
+    const float *raw;         // optional: the embeddings as the caller gave them, [nq_total, raw_dim] fp32 -- the kernel then rounds
+    int raw_dim;              // them to the rows' type and forms the inverse norms itself (what prep_queries_kernel does) and
+                              // reads neither queries nor q_inv
     int64_t row_begin, row_end;
     int64_t row_begin2, row_end2;  // optional second range, scanned behind the first in the same launch with its own group test
                                    // (group_filter2): a group's rows in the ordered part of a table, then the tail of rows added since
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
     char *q_lds = smem;
     const int q_bytes = NQ * p.ld * ESZ;
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem + (((size_t)q_bytes + 15) & ~(size_t)15));
-    uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * RG]
+    uint32_t *row_queue = reinterpret_cast<uint32_t *>(lists + (size_t)SCAN_WAVES * p.nq_out * p.k);  // [SCAN_WAVES][64 * RG], then NQ inverse norms
 
     constexpr bool M4 = LPR == 16;
     static_assert(!M4 || (NQ == 4 && DT != HVS_F32 && !DISTONLY), "the 4x4x4 MFMA mode takes four 16-bit embeddings");
@@ -439,15 +442,37 @@ __global__ __launch_bounds__(SCAN_THREADS, NQ <= 4 ? 4 : 2) void scan_kernel(Sca
     const int l = M4 ? (lane >> 2) : lane % LPR;    // its position among the LPR lanes of that row
     const int nq_total = p.nq_out * p.fold;
 
-    for (int i = tid; i < NQ * p.ld; i += SCAN_THREADS) {
-        const int q = i / p.ld;
-        Chunk<DT>::put_query(q_lds, i, q < nq_total ? p.queries[i] : 0.0f);
+    float *qinv_lds = reinterpret_cast<float *>(row_queue + SCAN_WAVES * 64 * RG);  // [NQ], behind the row queues
+    if (p.raw) {
+        // the embeddings as they came: a wave per embedding rounds them to the rows' type and sums the squares of the rounded
+        // values -- the lanes' partial sums in the order of prep_queries_kernel, so that both give the same bits
+        for (int q = wave; q < NQ; q += SCAN_WAVES) {
+            float s = 0.0f;
+            for (int c = lane; c < p.ld; c += 64) {
+                float v = 0.0f;
+                if (q < nq_total && c < p.raw_dim) {
+                    v = p.raw[(size_t)q * p.raw_dim + c];
+                    if (DT == HVS_F16) v = __half2float(__float2half_rn(v));
+                    else if (DT == HVS_BF16) v = hvs_bf16_to_float(hvs_float_to_bf16(v));
+                }
+                Chunk<DT>::put_query(q_lds, q * p.ld + c, v);
+                s = fmaf(v, v, s);
+            }
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) qinv_lds[q] = q < nq_total ? (float)(1.0 / sqrt((double)s)) : 0.0f;
+        }
+    } else {
+        for (int i = tid; i < NQ * p.ld; i += SCAN_THREADS) {
+            const int q = i / p.ld;
+            Chunk<DT>::put_query(q_lds, i, q < nq_total ? p.queries[i] : 0.0f);
+        }
+        if (tid < NQ) qinv_lds[tid] = tid < nq_total ? p.q_inv[tid] : 0.0f;
     }
     __syncthreads();
 
     float qinv[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) qinv[q] = q < nq_total ? p.q_inv[q] : 0.0f;
+    for (int q = 0; q < NQ; q++) qinv[q] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(qinv_lds[q])));  // wave-uniform: scalar registers
 
     volatile uint64_t *myL = lists + (size_t)wave * p.nq_out * p.k;
     const uint64_t thr_key = (uint64_t)p.thr_ord << 32;
@@ -834,7 +859,19 @@ __global__ void prep_queries_kernel(const float *__restrict__ src, float *__rest
     if (lane == 0) q_inv[q] = (float)(1.0 / sqrt((double)s));
 }
 
-int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int on_device, float **d_q, float **d_qinv) {
+// The embeddings of a call on the device, and whether they have been prepared yet (rounded to the rows' type with their
+// inverse norms: prep_queries_kernel).  A search that ends on the scan never launches the preparation: scan_kernel does
+// the same arithmetic in its prologue (ScanParams::raw), one launch less per call -- about 5 us of the 50 us that a
+// search of a small table takes.  Every other consumer calls queries_prepare first.
+struct PendingQueries {
+    const float *raw;  // [nq_total, dim] fp32 on the device
+    float *d_q;        // [nq_total, ld] prepared, valid once done
+    float *d_qinv;     // [nq_total]
+    int nq_total;
+    bool done;
+};
+
+static int queries_stage(hvs_index *idx, const float *queries, int nq_total, int on_device, PendingQueries *pq) {
     const size_t qbytes = (size_t)nq_total * idx->ld * 4;
     const size_t inv_off = (qbytes + 255) & ~(size_t)255;
     const size_t raw_off = (inv_off + (size_t)nq_total * 4 + 255) & ~(size_t)255;
@@ -846,10 +883,28 @@ int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int 
         HVS_HIP(hipMemcpyAsync((char *)ws + raw_off, queries, raw_bytes, hipMemcpyHostToDevice, idx->stream));
         src = (const float *)((char *)ws + raw_off);
     }
-    *d_q = (float *)ws;
-    *d_qinv = (float *)((char *)ws + inv_off);
-    prep_queries_kernel<<<(nq_total + 3) / 4, 256, 0, idx->stream>>>(src, *d_q, *d_qinv, nq_total, idx->dim, idx->ld, idx->dtype);
+    pq->raw = src;
+    pq->d_q = (float *)ws;
+    pq->d_qinv = (float *)((char *)ws + inv_off);
+    pq->nq_total = nq_total;
+    pq->done = false;
+    return 0;
+}
+
+static int queries_prepare(hvs_index *idx, PendingQueries *pq) {
+    if (!pq || pq->done) return 0;
+    prep_queries_kernel<<<(pq->nq_total + 3) / 4, 256, 0, idx->stream>>>(pq->raw, pq->d_q, pq->d_qinv, pq->nq_total, idx->dim, idx->ld, idx->dtype);
     HVS_HIP(hipGetLastError());
+    pq->done = true;
+    return 0;
+}
+
+int hvs_prepare_queries(hvs_index *idx, const float *queries, int nq_total, int on_device, float **d_q, float **d_qinv) {
+    PendingQueries pq;
+    HVS_TRY(queries_stage(idx, queries, nq_total, on_device, &pq));
+    HVS_TRY(queries_prepare(idx, &pq));
+    *d_q = pq.d_q;
+    *d_qinv = pq.d_qinv;
     return 0;
 }
 
@@ -933,6 +988,7 @@ static size_t scan_lds_bytes(int NQ, int ld, int esz, int nq_out, int k, int rg)
     size_t b = ((size_t)NQ * ld * esz + 15) & ~(size_t)15;
     b += (size_t)SCAN_WAVES * nq_out * k * 8;
     b += (size_t)SCAN_WAVES * 64 * rg * 4;  // live-row queues
+    b += 64;                                // the embeddings' inverse norms (up to 8)
     return b;
 }
 
@@ -945,7 +1001,7 @@ static const size_t LDS_LIMIT = 160 * 1024;
 static int search_scan_ranges(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                               const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist,
                               int64_t *d_ids, int32_t *d_count, void *lists, size_t lists_bytes, int64_t row_begin2, int64_t row_end2,
-                              int32_t group_filter2) {
+                              int32_t group_filter2, const PendingQueries *pq = nullptr) {
     // out-queries per pass: as many as fit 8 dot products and the LDS budget -- or 4, for 16-bit rows with
     // two to four embeddings per query: those passes run the 4x4x4 MFMA mode, which stays bandwidth-bound
     const bool m4 = idx->dtype != HVS_F32 && fold <= 4 && nq * fold >= 2;
@@ -1023,6 +1079,8 @@ static int search_scan_ranges(hvs_index *idx, const float *d_q, const float *d_q
         const int nqo = (nq - q0 < per_pass) ? nq - q0 : per_pass;
         p.queries = d_q + (size_t)q0 * fold * idx->ld;
         p.q_inv = d_qinv + (size_t)q0 * fold;
+        p.raw = (pq && !pq->done) ? pq->raw + (size_t)q0 * fold * idx->dim : nullptr;  // not prepared: the kernel does it
+        p.raw_dim = idx->dim;
         p.nq_out = nqo;
         HVS_TRY(hvs_prof_begin(idx));
         int g2 = 0;
@@ -1077,7 +1135,7 @@ extern "C" int hvs_search_filtered(hvs_index *idx, const float *queries, int nq,
 // pipe, filter pass + exact rescoring) as the header describes.
 static int search_range(hvs_index *idx, const float *d_q, const float *d_qinv, int nq, int fold, int k, int32_t group_filter,
                         const uint32_t *d_mask, float thr, int64_t row_begin, int64_t row_end, float *d_dist, int64_t *d_ids, int32_t *d_count,
-                        int algo) {
+                        int algo, PendingQueries *pq) {
     const int nq_total = nq * fold;
     bool use_mfma = false;
     if (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_MFMA_F32 || algo == HVS_ALGO_MFMA_SPLIT) {
@@ -1113,6 +1171,7 @@ static int search_range(hvs_index *idx, const float *d_q, const float *d_qinv, i
         // ... and where the split copy is in use, small k first tries one product instead of three: a filter pass over
         // the hi slabs alone, then exact fp32 scores of its candidates (MFMA_SPLIT keeps the three products)
         bool done = false;
+        HVS_TRY(queries_prepare(idx, pq));
         if (idx->dtype == HVS_F32 && (algo == HVS_ALGO_MFMA || algo == HVS_ALGO_AUTO) &&
             (algo == HVS_ALGO_MFMA || nq_total >= 16 || (idx->split && idx->split_n == idx->n)))
             HVS_TRY(hvs_search_rescore(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids,
@@ -1121,8 +1180,8 @@ static int search_range(hvs_index *idx, const float *d_q, const float *d_qinv, i
             HVS_TRY(hvs_search_mfma(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
                                     split_mode));
     } else
-        HVS_TRY(hvs_search_scan(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
-                                nullptr, 0));
+        HVS_TRY(search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count,
+                                   nullptr, 0, 0, 0, -1, pq));
 
     return 0;
 }
@@ -1191,8 +1250,10 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
     const float thr = hvs_ceil_to_float(max_distance);
     const int nq_total = nq * fold;
 
-    float *d_q = nullptr, *d_qinv = nullptr;
-    HVS_TRY(hvs_prepare_queries(idx, queries, nq_total, on_device, &d_q, &d_qinv));
+    PendingQueries pq;
+    HVS_TRY(queries_stage(idx, queries, nq_total, on_device, &pq));
+    if (getenv("HVS_NO_FUSED_PREP")) HVS_TRY(queries_prepare(idx, &pq));  // experiments: always the separate launch
+    float *d_q = pq.d_q, *d_qinv = pq.d_qinv;
 
     float *d_dist = out_dist;
     int64_t *d_ids = out_ids;
@@ -1225,7 +1286,7 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
         if (have_main && have_tail && filtered_search_takes_scan(idx, nq, fold, k, algo)) {
             // both, on the scan: one launch walks the group's range (no code test) and then the tail (with it).  Keys order
             // by row position, and the ordered part lies below the tail.
-            HVS_TRY(search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, d_dist, d_ids, d_count, nullptr, 0, tb, te, group_filter));
+            HVS_TRY(search_scan_ranges(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, d_dist, d_ids, d_count, nullptr, 0, tb, te, group_filter, &pq));
         } else if (have_main && have_tail) {
             // both, on the matrix pipe: each into lists of row positions, then one merge by (distance, position) -- the
             // ordered part lies below the tail, so ties still go to the lower position
@@ -1235,10 +1296,10 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
             HVS_TRY(hvs_ws_get(idx, 10, 2 * one, &pair));
             char *a = (char *)pair, *b = a + one;
             idx->emit_positions = true;
-            int rc = search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, (float *)a, (int64_t *)(a + o_i), (int32_t *)(a + o_c), algo);
+            int rc = search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, me, (float *)a, (int64_t *)(a + o_i), (int32_t *)(a + o_c), algo, &pq);
             if (rc == 0)
                 rc = search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, tb, te, (float *)b, (int64_t *)(b + o_i),
-                                  (int32_t *)(b + o_c), algo);
+                                  (int32_t *)(b + o_c), algo, &pq);
             idx->emit_positions = false;
             HVS_TRY(rc);
             HVS_TRY(hvs_prof_begin(idx));
@@ -1247,11 +1308,11 @@ int hvs_search_core(hvs_index *idx, const float *queries, int nq, int fold, int 
             HVS_HIP(hipGetLastError());
             HVS_TRY(hvs_prof_end(idx, HVS_PROF_MERGE));
         } else if (have_tail)
-            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, tb, te, d_dist, d_ids, d_count, algo));
+            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, tb, te, d_dist, d_ids, d_count, algo, &pq));
         else  // the group's range alone (an empty one gives counts of 0)
-            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, have_main ? me : mb, d_dist, d_ids, d_count, algo));
+            HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, -1, d_mask, thr, mb, have_main ? me : mb, d_dist, d_ids, d_count, algo, &pq));
     } else
-        HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, algo));
+        HVS_TRY(search_range(idx, d_q, d_qinv, nq, fold, k, group_filter, d_mask, thr, row_begin, row_end, d_dist, d_ids, d_count, algo, &pq));
 
     if (!on_device) {
         const size_t o_ids = (dist_bytes + 255) & ~(size_t)255;
