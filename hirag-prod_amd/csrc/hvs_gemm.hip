@@ -1338,9 +1338,15 @@ static int two_stage_splits(int qt, int64_t tiles, int slots) {
     return S < 1 ? 1 : S;
 }
 // Can the blocks of such a launch pool their first tiles (exchange_bound)?  Every block resident at once, at most 1024 and
-// at least 2 k published values per query (wn per block, or one per block where S * wn would pass 1024).
+// at least 1.5 k published values per query (wn per block, or one per block where S * wn would pass 1024).  (Any k values of
+// distinct rows bound the k-th distance; how many more there are decides how good the bound is.  With 2 k asked for, 4096
+// queries with the 40 candidates of the fp32 filter route -- 16 splits, 64 values -- took a pass over a sample instead; with
+// 1.5 k they pool: 500 k / 1M / 2M / 4M x 1536 rows 7.38 -> 6.56, 13.55 -> 12.36, 25.76 -> 24.32, 49.31 -> 47.19 ms per batch.
+// With k values, 64 of 64, the bound is too loose: 47.8 -> 50.6 ms at k = 64 on 4M rows.)
 static bool two_stage_can_pool(int qt, int S, int slots, int wn, int k) {
-    return (int64_t)qt * S <= slots && S <= 1024 && S * wn >= 2 * k && (S * wn <= 1024 || S >= 2 * k);
+    int fit = 150;  // published values per query, in percent of k
+    if (const char *e = getenv("HVS_XCHG_FIT")) fit = atoi(e) >= 100 ? atoi(e) : fit;  // experiments
+    return (int64_t)qt * S <= slots && S <= 1024 && (int64_t)S * wn * 100 >= (int64_t)fit * k && (S * wn <= 1024 || S >= 2 * k);
 }
 
 // LEAST over m <= 128 prepared embeddings of the distance to every row of [row_begin, row_end), in one pass over the
@@ -1548,7 +1554,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
     if (const char *e = getenv("HVS_F32_TILE")) big = kdt == HVS_F32 ? atoi(e) == 256 && nA > Tile128::BM : big;  // 128 / 256 forces the shape for fp32 rows
     bool small = kdt != HVS_F32 && nA <= 32;  // measured: 10-13 % faster than Tile128 up to 16 embeddings, even at 32, slower at 64
     if (const char *e = getenv("HVS_TILE")) small = kdt != HVS_F32 && atoi(e) == 64;
-    // A range so short that the blocks of the tile at hand could not pool their first tiles (fewer than 2 k published
+    // A range so short that the blocks of the tile at hand could not pool their first tiles (fewer than 1.5 k published
     // values per query) takes a smaller tile that can: without a common bound every score of such a launch is a survivor
     // (the dense copy of 9 800 live rows of a tail, 256 queries, k = 100: 0.39 ms on 32 blocks of the 256 x 256 tile).
     if (!stream && kdt != HVS_F32 && !getenv("HVS_TILE") && !getenv("HVS_NO_XCHG")) {
@@ -1589,7 +1595,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         return two_stage_splits(p.QT, T, slots_of_tile);
     };
     // can the blocks of such a launch pool their first tiles (exchange_bound)?  16-bit operands on the two-stage kernel,
-    // every block resident at once, at most 1024 and at least 2 k published values per query
+    // every block resident at once, at most 1024 and at least 1.5 k published values per query
     auto xchg_fits = [&](int S) -> bool { return !stream && kdt != HVS_F32 && two_stage_can_pool(p.QT, S, slots_of_tile, wn_of_tile, k); };
     // One pass of the kernel over rows [rb, re) and the merge of its per-block lists into out_*.
     auto run_pass = [&](SearchParams pp, int64_t rb, int64_t re, const float *tau0, float *o_dist, int64_t *o_ids, int32_t *o_count) -> int {
@@ -1610,7 +1616,7 @@ int hvs_search_mfma(hvs_index *idx, const float *d_q, const float *d_qinv, int n
         const size_t ls_bytes = lockstep ? (size_t)8 * S * 4 : 0;
         // the blocks pool what their first tile shows (exchange_bound): 16-bit operands, streams so short that a block's own
         // bound gets nowhere (the condition a pass over a sample is taken under, which this replaces), every block resident
-        // and with a tile of its own, and at least 2 k published values per query
+        // and with a tile of its own, and at least 1.5 k published values per query
         const int xw = S * wn_of_tile <= 1024 ? wn_of_tile : 1;
         const int xm = S * xw;
         pp.xchg_w = xw;

@@ -112,3 +112,37 @@ def test_blocks_in_lockstep_or_free_running_give_the_same_answers(hvs, dtype):
     for i in (0, 255, 256, nq - 1):
         parity.check_topk(locked[0][i], locked[1][i], locked[2][i], parity.full_distances(rows, q[i], dtype), k, label=f"{dtype} lockstep q={i}")
     idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_pooling_with_between_one_and_a_half_and_two_k_values(hvs, dtype):
+    """16 query tiles of 256 leave 16 splits of the rows: 64 published values per query, with k = 40 more than 1.5 k and fewer
+    than 2 k.  The launch pools its first tiles (one search launch, no pass over a sample) and gives the answers of the launch
+    that does not; a sample of the queries is held to the oracle."""
+    rng = np.random.default_rng(4040)
+    n, d, nq, k = 60_000 + 11, 64, 3900, 40
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[7] = 0.0
+    rows[1000:1100] = rows[3]
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[1] = rows[3]
+    idx = hvs.HvsIndex(d, dtype)
+    idx.add(rows)
+    from hirag_prod_amd import _lib
+
+    idx.profile(True)
+    idx.profile_reset()
+    dist, ids, cnt = idx.search(q, k=k, algo="mfma")
+    _, launches = idx.profile_get(_lib.HVS_PROF_MFMA_SEARCH)
+    idx.profile(False)
+    assert launches == 1, f"{launches} search launches: the blocks did not pool their first tiles"
+    os.environ["HVS_NO_XCHG"] = "1"
+    try:
+        r_dist, r_ids, r_cnt = idx.search(q, k=k, algo="mfma")
+    finally:
+        del os.environ["HVS_NO_XCHG"]
+    assert np.array_equal(cnt, r_cnt) and np.array_equal(ids, r_ids) and np.array_equal(dist, r_dist)
+    sample = np.concatenate([[0, 1, 2], rng.choice(nq, 21, replace=False)])
+    dm = parity.distance_matrix(rows, q[sample], dtype)
+    for j, i in enumerate(sample):
+        parity.check_topk(dist[i], ids[i], cnt[i], dm[j], k, label=f"{dtype} query {i}")
